@@ -1,0 +1,87 @@
+"""ctypes binding of libfy_cosy3.so (include/fy_cosy3.h).
+
+The product path has no CPU fallback: if the library is missing this raises,
+and every call checks the status code and raises FyError with fy_last_error().
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfy_cosy3.so")
+
+
+class FyError(RuntimeError):
+    pass
+
+
+class FyTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class HiftConfig(C.Structure):
+    _fields_ = [("mel", C.c_int32), ("base", C.c_int32), ("harmonics", C.c_int32), ("sampling_rate", C.c_int32),
+                ("nsf_alpha", C.c_float), ("nsf_sigma", C.c_float), ("voiced_thr", C.c_float),
+                ("ups", C.c_int32 * 3), ("up_k", C.c_int32 * 3), ("n_fft", C.c_int32), ("hop", C.c_int32),
+                ("rb_k", C.c_int32 * 3), ("rb_d", C.c_int32 * 3), ("src_rb_k", C.c_int32 * 3),
+                ("lrelu", C.c_float), ("audio_limit", C.c_float), ("pre_look_right", C.c_int32), ("f0_ch", C.c_int32)]
+
+
+FY_PRECISE = 1
+FY_DIRECT = 2
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FyError(f"{LIB_PATH} is missing: build it with `python -m fangyan_tts_amd.build` "
+                          "(there is no CPU fallback for the product path)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.fy_last_error.restype = C.c_char_p
+        _declare(_lib)
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise FyError(f"libfy_cosy3 error {rc}: {lib().fy_last_error().decode(errors='replace')}")
+
+
+def _declare(L):
+    vp, i32, u32, f32p, i32p = C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.POINTER(C.c_int32)
+    L.fy_version.restype = C.c_int
+    L.fy_hift_default_config.argtypes = [C.POINTER(HiftConfig)]
+    L.fy_hift_default_config.restype = None
+    L.fy_hift_create.argtypes = [C.POINTER(vp), C.POINTER(HiftConfig), C.POINTER(FyTensor), i32, i32, i32, vp]
+    L.fy_hift_destroy.argtypes = [vp]
+    L.fy_hift_destroy.restype = None
+    L.fy_hift_infer.argtypes = [vp, f32p, i32p, i32, i32, f32p, f32p, f32p, f32p, u32, vp]
+    L.fy_hift_f0.argtypes = [vp, f32p, i32p, i32, i32, f32p, vp]
+    L.fy_hift_source.argtypes = [vp, f32p, i32p, i32, i32, f32p, f32p, f32p, vp]
+    L.fy_hift_decode.argtypes = [vp, f32p, f32p, i32p, i32, i32, f32p, u32, vp]
+    L.fy_hift_tap.argtypes = [vp, C.c_char_p, f32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]
+    L.fy_hift_resblock.argtypes = [vp, i32, f32p, f32p, i32, i32, u32, vp]
+
+
+def tensor_table(weights):
+    """dict name -> contiguous fp32 CUDA torch tensor  ->  (FyTensor array, keep-alive list)."""
+    import torch
+    arr = (FyTensor * len(weights))()
+    keep = []
+    for i, (name, t) in enumerate(weights.items()):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise FyError(f"weight {name}: need a contiguous fp32 tensor on the GPU")
+        nb = name.encode()
+        keep.append((nb, t))
+        arr[i].name = nb
+        arr[i].data = t.data_ptr()
+        arr[i].ndim = max(t.dim(), 1)
+        for k, s in enumerate(t.shape):
+            arr[i].shape[k] = s
+    return arr, keep
+
+
+def int_array(values):
+    return (C.c_int32 * len(values))(*[int(v) for v in values])

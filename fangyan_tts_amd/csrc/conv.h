@@ -1,0 +1,48 @@
+// 1-D causal convolution kernels over channels-last fp32 activations.
+//   conv1d_f32_direct : exact fp32 VALU kernel, any shape (f0 predictor, source
+//                       down-samplers, conv_post, PreLookahead) and the on-GPU
+//                       cross-check of the MFMA kernel.
+//   conv1d_bf16_mfma  : implicit GEMM on v_mfma_f32_32x32x16_bf16; the input tile
+//                       (+ causal halo) is activated once and staged in LDS as
+//                       bf16, the taps walk LDS rows, weights stream from L2 in
+//                       fragment order.  fp32 in HBM on both sides.
+#pragma once
+#include "common.h"
+
+struct ConvDesc {
+    // input: element (b, row, c) at x + b*x_bs + row*x_ld + c   (fp32)
+    const float* x; long x_bs; int x_ld;
+    int L_in; const int* in_len;          // rows >= in_len[b] (or L_in) and rows < 0 read as zero
+    // output, same addressing
+    float* y; long y_bs; int y_ld;
+    int L_out; const int* out_len;        // conv output rows computed for batch b
+    const float* resid; long r_bs; int r_ld;
+    const float* bias;                    // [Cout] or null
+    const float* alpha;                   // snake alpha [Cin] (pre_act == ACT_SNAKE)
+    int B, Cin, Cout, KW, dil, stride, up, pad_left, groups;
+    int pre_act; float pre_slope;
+    int post_act; float post_slope;
+    int add_resid;                        // v += resid[q]
+    int accumulate;                       // y[q] += v*scale  instead of  y[q] = v*scale
+    float out_scale;
+    int reflect1;                         // ReflectionPad1d((1,0)) of the conv output: row p -> q = p+1, q=0 <- p=1
+};
+
+// weights of one conv in both kernel layouts (either may be null)
+struct ConvW {
+    float* w_dir = nullptr;    // [KW][Cin_g][Cout_pad4] fp32
+    bf16_t* w_mfma = nullptr;  // [g][KW][Cin_g_pad/16][Cout_g/32][512] bf16 (B-fragment order)
+    float* bias = nullptr;     // [Cout]
+    int Cin = 0, Cout = 0, KW = 0, groups = 1;
+    int cout_pad4() const { return (Cout + 3) & ~3; }
+    int cin_g_pad() const { return ((Cin / groups + 15) / 16) * 16; }
+};
+
+// pack from the reference layout (Cout, Cin/groups, KW) fp32; g != null folds weight_norm:
+// w = g * v / ||v|| per output channel (torch._weight_norm, dim 0)
+int conv_pack(ConvW& cw, const float* v, const float* g, const float* bias, int Cout, int Cin, int KW, int groups,
+              bool want_direct, bool want_mfma, hipStream_t st);
+void conv_free(ConvW& cw);
+
+int conv1d_f32_direct(const ConvDesc& d, const ConvW& w, hipStream_t st);
+int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_t st);

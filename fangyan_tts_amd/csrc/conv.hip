@@ -1,0 +1,395 @@
+// Causal 1-D convolutions for the HiFT vocoder, the f0 predictor, PreLookahead
+// and the DiT convolutional position embedding.  See conv.h.
+//
+// Reference semantics: CausalConv1d / CausalConv1dDownSample / CausalConv1dUpsample,
+// CosyVoice/cosyvoice/transformer/convolution.py:150-258 (zero pad on the causal
+// side, nearest-repeat upsample before the conv), ResBlock / Snake fusion points
+// from hifigan/generator.py:110-117, 682-700.
+#include "conv.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
+
+__device__ __forceinline__ int floordiv(int a, int b) {   // b > 0
+    return a >= 0 ? a / b : -((-a + b - 1) / b);
+}
+
+__device__ __forceinline__ float apply_pre(float v, int act, float slope, float alpha) {
+    if (act == ACT_LEAKY) return act_leaky(v, slope);
+    if (act == ACT_SNAKE) return act_snake(v, alpha);
+    return v;
+}
+__device__ __forceinline__ float apply_post(float v, int act, float slope) {
+    if (act == ACT_ELU) return act_elu(v);
+    if (act == ACT_LEAKY) return act_leaky(v, slope);
+    if (act == ACT_MISH) return act_mish(v);
+    return v;
+}
+
+__device__ __forceinline__ void conv_store(const ConvDesc& d, int b, int p, int co, float v) {
+    // epilogue shared by both kernels: bias already added by the caller
+    v = apply_post(v, d.post_act, d.post_slope);
+    int q = d.reflect1 ? p + 1 : p;
+    long yo = (long)b * d.y_bs + (long)q * d.y_ld + co;
+    float r = v;
+    if (d.add_resid) r += d.resid[(long)b * d.r_bs + (long)q * d.r_ld + co];
+    r *= d.out_scale;
+    if (d.accumulate) d.y[yo] += r; else d.y[yo] = r;
+    if (d.reflect1 && p == 1) {                      // q = 0 mirrors conv row 1
+        long y0 = (long)b * d.y_bs + co;
+        float r0 = v;
+        if (d.add_resid) r0 += d.resid[(long)b * d.r_bs + co];
+        r0 *= d.out_scale;
+        if (d.accumulate) d.y[y0] += r0; else d.y[y0] = r0;
+    }
+}
+
+// =============================================================================
+// fp32 direct kernel: block = 64 positions x 64 output channels, 4x4 per thread
+// =============================================================================
+#define DIR_TP 64
+#define DIR_TCO 64
+#define DIR_CC 16
+
+__global__ __launch_bounds__(256) void conv1d_f32_direct_k(ConvDesc d, const float* __restrict__ w, int cout_pad, int nrows_max) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];      // [nrows_max][DIR_CC]
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int b = blockIdx.z;
+    const int Cin_g = d.Cin / d.groups, Cout_g = d.Cout / d.groups;
+    const int tiles_per_g = (Cout_g + DIR_TCO - 1) / DIR_TCO;
+    const int g = blockIdx.y / tiles_per_g;
+    const int co_in_g = (blockIdx.y % tiles_per_g) * DIR_TCO + tx * 4;
+    const int co = g * Cout_g + co_in_g;
+    const int ci_base = g * Cin_g;
+    const int p0 = blockIdx.x * DIR_TP;
+    const int n_out = d.out_len ? d.out_len[b] : d.L_out;
+    if (p0 >= n_out) return;
+    const int n_in = d.in_len ? d.in_len[b] : d.L_in;
+    const int row_lo = floordiv(p0 * d.stride - d.pad_left, d.up);
+    const int row_hi = floordiv((p0 + DIR_TP - 1) * d.stride + (d.KW - 1) * d.dil - d.pad_left, d.up);
+    const int nrows = row_hi - row_lo + 1;
+    const float* xb = d.x + (long)b * d.x_bs;
+
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+    for (int ci0 = 0; ci0 < Cin_g; ci0 += DIR_CC) {
+        const int ccn = min(DIR_CC, Cin_g - ci0);
+        __syncthreads();
+        for (int idx = tid; idx < nrows * DIR_CC; idx += 256) {
+            int r = idx / DIR_CC, c = idx % DIR_CC;
+            int row = row_lo + r;
+            float v = 0.f;
+            if (row >= 0 && row < n_in && c < ccn) {
+                int ci = ci_base + ci0 + c;
+                v = xb[(long)row * d.x_ld + ci];
+                v = apply_pre(v, d.pre_act, d.pre_slope, d.pre_act == ACT_SNAKE ? d.alpha[ci] : 0.f);
+            }
+            xs[idx] = v;
+        }
+        __syncthreads();
+        if (co_in_g < Cout_g) {
+            for (int t = 0; t < d.KW; ++t) {
+                int rr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int s = (p0 + ty * 4 + i) * d.stride + t * d.dil - d.pad_left;
+                    rr[i] = ((d.up == 1) ? s : floordiv(s, d.up)) - row_lo;
+                }
+                const float* wt = w + ((long)(t * Cin_g + ci0)) * cout_pad + co;
+                for (int c = 0; c < ccn; ++c) {
+                    float4 wv = *reinterpret_cast<const float4*>(wt + (long)c * cout_pad);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float xv = xs[rr[i] * DIR_CC + c];
+                        acc[i][0] = fmaf(xv, wv.x, acc[i][0]);
+                        acc[i][1] = fmaf(xv, wv.y, acc[i][1]);
+                        acc[i][2] = fmaf(xv, wv.z, acc[i][2]);
+                        acc[i][3] = fmaf(xv, wv.w, acc[i][3]);
+                    }
+                }
+            }
+        }
+    }
+    if (co_in_g >= Cout_g) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int p = p0 + ty * 4 + i;
+        if (p >= n_out) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int c = co + j;
+            if (co_in_g + j < Cout_g && c < d.Cout) conv_store(d, b, p, c, acc[i][j] + (d.bias ? d.bias[c] : 0.f));
+        }
+    }
+}
+
+int conv1d_f32_direct(const ConvDesc& d, const ConvW& w, hipStream_t st) {
+    FY_CHECK(w.w_dir != nullptr, FY_ERR_STATE, "conv1d_f32_direct: weights not packed for the direct kernel");
+    FY_CHECK(d.Cin == w.Cin && d.Cout == w.Cout && d.KW == w.KW && d.groups == w.groups, FY_ERR_ARG,
+             "conv1d_f32_direct: descriptor (%d,%d,%d,g%d) != weights (%d,%d,%d,g%d)", d.Cin, d.Cout, d.KW, d.groups,
+             w.Cin, w.Cout, w.KW, w.groups);
+    FY_CHECK(d.up >= 1 && d.stride >= 1 && d.dil >= 1 && d.B >= 1 && d.L_out >= 1, FY_ERR_ARG, "conv1d_f32_direct: bad geometry");
+    FY_CHECK((d.Cout / d.groups) % 4 == 0 || d.groups == 1, FY_ERR_ARG, "conv1d_f32_direct: Cout/groups must be a multiple of 4");
+    int nrows_max = ((DIR_TP - 1) * d.stride + (d.KW - 1) * d.dil) / d.up + 3;
+    size_t lds = (size_t)nrows_max * DIR_CC * sizeof(float);
+    FY_CHECK(lds <= 160 * 1024, FY_ERR_ARG, "conv1d_f32_direct: input tile needs %zu B of LDS", lds);
+    int Cout_g = d.Cout / d.groups;
+    dim3 grid(cdiv(d.L_out, DIR_TP), d.groups * cdiv(Cout_g, DIR_TCO), d.B);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)conv1d_f32_direct_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(conv1d_f32_direct_k, grid, dim3(256), lds, st, d, w.w_dir, w.cout_pad4(), nrows_max);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+// =============================================================================
+// bf16 MFMA implicit-GEMM kernel
+//   block = WAVES_P x WAVES_C waves, each wave a 64-position x 64-channel tile
+//   (2x2 v_mfma_f32_32x32x16_bf16 accumulators).  D[pos][co] = sum_{t,ci}
+//   X[pos + t*dil - pad][ci] * W[t][ci][co]; A = activations out of LDS,
+//   B = weights in fragment order straight from L2.
+// =============================================================================
+#define MF_CC 128                      // input channels staged per pass
+// LDS row pitch in bytes: the staged channels as bf16 + a 16-B pad against bank conflicts
+static __host__ __device__ inline int mf_rowb(int cin_gp) { return (cin_gp < MF_CC ? cin_gp : MF_CC) * 2 + 16; }
+
+template <int WAVES_P, int WAVES_C, bool PRECISE>
+__global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(ConvDesc d, const bf16_t* __restrict__ wp, int nrows_max) {
+    constexpr int TP = WAVES_P * 64, TCO = WAVES_C * 64, NT = WAVES_P * WAVES_C * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];    // hi tile [nrows_max][MF_ROWB] (+ lo tile when PRECISE)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wpi = wid / WAVES_C, wci = wid % WAVES_C;
+    const int b = blockIdx.z;
+    const int Cin_g = d.Cin / d.groups, Cout_g = d.Cout / d.groups;
+    const int Cin_gp = ((Cin_g + 15) / 16) * 16;
+    const int C16 = Cin_gp / 16, N32 = Cout_g / 32;
+    const int MF_ROWB = mf_rowb(Cin_gp);
+    const int tiles_per_g = (Cout_g + TCO - 1) / TCO;
+    const int g = blockIdx.y / tiles_per_g;
+    const int n32_base = (blockIdx.y % tiles_per_g) * (TCO / 32) + wci * 2;   // this wave's first 32-column tile in the group
+    const int ci_base = g * Cin_g;
+    const int p0 = blockIdx.x * TP;
+    const int n_out = d.out_len ? d.out_len[b] : d.L_out;
+    if (p0 >= n_out) return;
+    const int n_in = d.in_len ? d.in_len[b] : d.L_in;
+    const int row_lo = floordiv(p0 - d.pad_left, d.up);
+    const int row_hi = floordiv(p0 + TP - 1 + (d.KW - 1) * d.dil - d.pad_left, d.up);
+    const int nrows = row_hi - row_lo + 1;
+    const float* xb = d.x + (long)b * d.x_bs;
+    char* lo_tile = smem + (size_t)nrows_max * MF_ROWB;
+    const bool wave_live = n32_base < N32;          // whole wave beyond the group's channels: only helps staging
+    const bool tile1_live = n32_base + 1 < N32;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int kh = lane >> 5, lr = lane & 31;
+    for (int ci0 = 0; ci0 < Cin_gp; ci0 += MF_CC) {
+        const int ccn = min(MF_CC, Cin_gp - ci0);          // multiple of 16
+        const int q4 = ccn / 4;
+        __syncthreads();
+        for (int idx = tid; idx < nrows * q4; idx += NT) {
+            int r = idx / q4, c4 = (idx % q4) * 4;
+            int row = row_lo + r;
+            int ci = ci0 + c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row >= 0 && row < n_in && ci < Cin_g) {
+                v = *reinterpret_cast<const float4*>(xb + (long)row * d.x_ld + ci_base + ci);
+                if (d.pre_act == ACT_LEAKY) {
+                    v.x = act_leaky(v.x, d.pre_slope); v.y = act_leaky(v.y, d.pre_slope);
+                    v.z = act_leaky(v.z, d.pre_slope); v.w = act_leaky(v.w, d.pre_slope);
+                } else if (d.pre_act == ACT_SNAKE) {
+                    float4 a = *reinterpret_cast<const float4*>(d.alpha + ci_base + ci);
+                    v.x = act_snake(v.x, a.x); v.y = act_snake(v.y, a.y);
+                    v.z = act_snake(v.z, a.z); v.w = act_snake(v.w, a.w);
+                }
+            }
+            bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
+            uint2 pk;
+            pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+            *reinterpret_cast<uint2*>(smem + (size_t)r * MF_ROWB + c4 * 2) = pk;
+            if (PRECISE) {
+                bf16_t l0 = f32_to_bf16(v.x - bf16_to_f32(h0)), l1 = f32_to_bf16(v.y - bf16_to_f32(h1));
+                bf16_t l2 = f32_to_bf16(v.z - bf16_to_f32(h2)), l3 = f32_to_bf16(v.w - bf16_to_f32(h3));
+                pk.x = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                pk.y = (uint32_t)l2 | ((uint32_t)l3 << 16);
+                *reinterpret_cast<uint2*>(lo_tile + (size_t)r * MF_ROWB + c4 * 2) = pk;
+            }
+        }
+        __syncthreads();
+        if (!wave_live) continue;
+        const int c16_0 = ci0 / 16;
+        for (int t = 0; t < d.KW; ++t) {
+            int arow[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                int s = p0 + wpi * 64 + mi * 32 + lr + t * d.dil - d.pad_left;
+                arow[mi] = ((d.up == 1) ? s : floordiv(s, d.up)) - row_lo;
+            }
+            const bf16_t* wt = wp + ((((long)g * d.KW + t) * C16 + c16_0) * N32 + n32_base) * 512 + lane * 8;
+            for (int kk = 0; kk < ccn / 16; ++kk) {
+                frag_ab bfr[2];
+                bfr[0] = *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512);
+                bfr[1] = tile1_live ? *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512 + 512) : bfr[0];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    size_t off = (size_t)arow[mi] * MF_ROWB + (kk * 16 + kh * 8) * 2;
+                    frag_ab a = *reinterpret_cast<const frag_ab*>(smem + off);
+                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[0], acc[mi][0], 0, 0, 0);
+                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[1], acc[mi][1], 0, 0, 0);
+                    if (PRECISE) {
+                        frag_ab al = *reinterpret_cast<const frag_ab*>(lo_tile + off);
+                        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr[0], acc[mi][0], 0, 0, 0);
+                        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr[1], acc[mi][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!wave_live) return;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        if (ni == 1 && !tile1_live) break;
+        const int co = g * Cout_g + (n32_base + ni) * 32 + lr;
+        const float bv = d.bias ? d.bias[co] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int p = p0 + wpi * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (p < n_out) conv_store(d, b, p, co, acc[mi][ni][r] + bv);
+            }
+        }
+    }
+}
+
+template <int WP, int WC, bool PR>
+static int launch_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st) {
+    constexpr int TP = WP * 64, TCO = WC * 64;
+    int nrows_max = (TP - 1 + (d.KW - 1) * d.dil) / d.up + 3;
+    const int Cin_gp = ((d.Cin / d.groups + 15) / 16) * 16;
+    size_t lds = (size_t)nrows_max * mf_rowb(Cin_gp) * (PR ? 2 : 1);
+    FY_CHECK(lds <= 160 * 1024, FY_ERR_ARG, "conv1d_bf16_mfma: input tile needs %zu B of LDS", lds);
+    int Cout_g = d.Cout / d.groups;
+    dim3 grid(cdiv(d.L_out, TP), d.groups * cdiv(Cout_g, TCO), d.B);
+    auto kern = conv1d_bf16_mfma_k<WP, WC, PR>;
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, grid, dim3(WP * WC * 64), lds, st, d, w.w_mfma, nrows_max);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_t st) {
+    FY_CHECK(w.w_mfma != nullptr, FY_ERR_STATE, "conv1d_bf16_mfma: weights not packed for the MFMA kernel");
+    FY_CHECK(d.Cin == w.Cin && d.Cout == w.Cout && d.KW == w.KW && d.groups == w.groups, FY_ERR_ARG,
+             "conv1d_bf16_mfma: descriptor (%d,%d,%d,g%d) != weights (%d,%d,%d,g%d)", d.Cin, d.Cout, d.KW, d.groups,
+             w.Cin, w.Cout, w.KW, w.groups);
+    FY_CHECK(d.stride == 1 && d.up >= 1 && d.dil >= 1 && d.B >= 1 && d.L_out >= 1, FY_ERR_ARG, "conv1d_bf16_mfma: bad geometry");
+    int Cin_g = d.Cin / d.groups, Cout_g = d.Cout / d.groups;
+    FY_CHECK(Cout_g % 32 == 0 && Cin_g % 4 == 0 && d.x_ld % 4 == 0, FY_ERR_ARG,
+             "conv1d_bf16_mfma: Cout/groups %% 32, Cin/groups %% 4 and the input pitch %% 4 must be 0");
+    FY_CHECK(((uintptr_t)d.x & 15) == 0 && (d.x_bs % 4) == 0, FY_ERR_ARG, "conv1d_bf16_mfma: input must be 16-B aligned");
+    if (Cout_g >= 128) {
+        return precise ? launch_mfma<2, 2, true>(d, w, st) : launch_mfma<2, 2, false>(d, w, st);
+    }
+    return precise ? launch_mfma<4, 1, true>(d, w, st) : launch_mfma<4, 1, false>(d, w, st);
+}
+
+// =============================================================================
+// weight packing (load time)
+// =============================================================================
+__global__ void wn_scale_k(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ scale, int per_co) {
+    // scale[co] = g[co] / ||v[co]||  (torch._weight_norm over dims != 0); 1 when g is null
+    __shared__ double red[256];
+    int co = blockIdx.x;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < per_co; i += 256) {
+        double x = v[(long)co * per_co + i];
+        s += x * x;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) scale[co] = g ? (float)((double)g[co] / sqrt(red[0])) : 1.0f;
+}
+
+__global__ void pack_dir_k(const float* __restrict__ v, const float* __restrict__ scale, float* __restrict__ out,
+                           int Cout, int Cin_g, int KW, int cout_pad) {
+    long n = (long)KW * Cin_g * cout_pad;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        int co = i % cout_pad;
+        long r = i / cout_pad;
+        int ci = r % Cin_g, t = r / Cin_g;
+        out[i] = co < Cout ? v[((long)co * Cin_g + ci) * KW + t] * scale[co] : 0.f;
+    }
+}
+
+__global__ void pack_mfma_k(const float* __restrict__ v, const float* __restrict__ scale, bf16_t* __restrict__ out,
+                            int Cout, int Cin_g, int KW, int groups) {
+    const int Cout_g = Cout / groups, Cin_gp = ((Cin_g + 15) / 16) * 16, C16 = Cin_gp / 16, N32 = Cout_g / 32;
+    long n = (long)groups * KW * C16 * N32 * 512;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        int j = i & 7, l = (i >> 3) & 63;
+        long r = i >> 9;
+        int n32 = r % N32; r /= N32;
+        int c16 = r % C16; r /= C16;
+        int t = r % KW;
+        int g = r / KW;
+        int ci = c16 * 16 + (l >> 5) * 8 + j;
+        int co = g * Cout_g + n32 * 32 + (l & 31);
+        float x = ci < Cin_g ? v[((long)co * Cin_g + ci) * KW + t] * scale[co] : 0.f;
+        out[i] = f32_to_bf16(x);
+    }
+}
+
+int conv_pack(ConvW& cw, const float* v, const float* g, const float* bias, int Cout, int Cin, int KW, int groups,
+              bool want_direct, bool want_mfma, hipStream_t st) {
+    FY_CHECK(Cout > 0 && Cin > 0 && KW > 0 && groups > 0 && Cin % groups == 0 && Cout % groups == 0, FY_ERR_ARG,
+             "conv_pack: bad shape (%d,%d,%d,g%d)", Cout, Cin, KW, groups);
+    cw.Cin = Cin; cw.Cout = Cout; cw.KW = KW; cw.groups = groups;
+    const int Cin_g = Cin / groups;
+    float* scale = nullptr;
+    HIP_TRY(hipMalloc(&scale, Cout * sizeof(float)));
+    hipLaunchKernelGGL(wn_scale_k, dim3(Cout), dim3(256), 0, st, v, g, scale, Cin_g * KW);
+    if (bias) {
+        HIP_TRY(hipMalloc(&cw.bias, Cout * sizeof(float)));
+        HIP_TRY(hipMemcpyAsync(cw.bias, bias, Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    if (want_direct) {
+        long n = (long)KW * Cin_g * cw.cout_pad4();
+        HIP_TRY(hipMalloc(&cw.w_dir, n * sizeof(float)));
+        hipLaunchKernelGGL(pack_dir_k, dim3((int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, v, scale,
+                           cw.w_dir, Cout, Cin_g, KW, cw.cout_pad4());
+    }
+    if (want_mfma) {
+        FY_CHECK((Cout / groups) % 32 == 0, FY_ERR_ARG, "conv_pack: MFMA layout needs Cout/groups %% 32 == 0 (got %d)", Cout / groups);
+        long n = (long)groups * KW * (cw.cin_g_pad() / 16) * (Cout / groups / 32) * 512;
+        HIP_TRY(hipMalloc(&cw.w_mfma, n * sizeof(bf16_t)));
+        hipLaunchKernelGGL(pack_mfma_k, dim3((int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, v, scale,
+                           cw.w_mfma, Cout, Cin_g, KW, groups);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipFree(scale));
+    return FY_OK;
+}
+
+void conv_free(ConvW& cw) {
+    if (cw.w_dir) (void)hipFree(cw.w_dir);
+    if (cw.w_mfma) (void)hipFree(cw.w_mfma);
+    if (cw.bias) (void)hipFree(cw.bias);
+    cw = ConvW();
+}

@@ -1,0 +1,559 @@
+// HiFT vocoder engine: CausalHiFTGenerator.inference (finalize=True),
+// CosyVoice/cosyvoice/hifigan/generator.py:713-726, as a batch of ragged
+// utterances.  Activations live in HBM as fp32 channels-last (B, L, C); every
+// convolution reads its input once and writes its output once, with the
+// neighbouring element-wise work (Snake, leaky-relu, nearest upsample, reflect
+// pad, residual, source fusion, the /3 average) folded into it.
+#include "conv.h"
+#include "runtime.h"
+#include <math.h>
+
+#define N_UP 3
+#define N_RB 3
+#define N_DIL 3
+
+struct HiftConvs {
+    ConvW conv_pre, conv_post;
+    ConvW ups[N_UP], source_downs[N_UP];
+    ConvW f0c[5];
+    struct RB { ConvW c1[N_DIL], c2[N_DIL]; float *a1[N_DIL], *a2[N_DIL]; } src_rb[N_UP], rb[N_UP * N_RB];
+};
+
+struct fy_hift {
+    fy_hift_config cfg;
+    int max_batch = 0, max_frames = 0;
+    int up_total = 0, stft_per_frame = 0;
+    HiftConvs w;
+    float *cls_w = nullptr, *cls_b = nullptr;       // f0 classifier (1, f0_ch), (1)
+    float *lin_w = nullptr, *lin_b = nullptr;       // m_source.l_linear (1, H+1), (1)
+    DevPool pool, wpool;
+    // activations (channels-last)
+    float *mel_cl, *f0a, *f0b, *f0, *rad_phase, *source, *s_stft, *x_pre, *post, *spec;
+    float *xs[N_UP], *x[N_UP], *r[N_UP], *xt[N_UP], *si[N_UP];
+    int *lens;                                       // device: [6][max_batch] = F, L0, L1, L2conv, L2, S
+    int B = 0, Fmax = 0;                             // of the last call (for taps)
+    int L(int stage, int F) const {                  // rows of stage tensors for F frames
+        int l = F;
+        for (int i = 0; i <= stage; ++i) l *= cfg.ups[i];
+        return stage == N_UP - 1 ? l + 1 : l;
+    }
+    int C(int stage) const { return cfg.base >> (stage + 1); }
+    ~fy_hift();
+};
+
+extern "C" void fy_hift_default_config(fy_hift_config* c) {
+    memset(c, 0, sizeof(*c));
+    c->mel = 80; c->base = 512; c->harmonics = 8; c->sampling_rate = 24000;
+    c->nsf_alpha = 0.1f; c->nsf_sigma = 0.003f; c->voiced_thr = 10.f;
+    const int ups[3] = {8, 5, 3}, upk[3] = {16, 11, 7}, rbk[3] = {3, 7, 11}, rbd[3] = {1, 3, 5}, srk[3] = {7, 7, 11};
+    for (int i = 0; i < 3; ++i) { c->ups[i] = ups[i]; c->up_k[i] = upk[i]; c->rb_k[i] = rbk[i]; c->rb_d[i] = rbd[i]; c->src_rb_k[i] = srk[i]; }
+    c->n_fft = 16; c->hop = 4; c->lrelu = 0.1f; c->audio_limit = 0.99f; c->pre_look_right = 4; c->f0_ch = 512;
+}
+
+static void source_down_shape(const fy_hift_config& c, int i, int* k, int* stride) {
+    // generator.py:642-652: downsample_cum_rates[::-1][i]
+    int rates[N_UP] = {1, c.ups[2], c.ups[1]};
+    int cum[N_UP] = {rates[0], rates[0] * rates[1], rates[0] * rates[1] * rates[2]};
+    int u = cum[N_UP - 1 - i];
+    if (u == 1) { *k = 1; *stride = 1; } else { *k = 2 * u; *stride = u; }
+}
+
+fy_hift::~fy_hift() {
+    conv_free(w.conv_pre); conv_free(w.conv_post);
+    for (int i = 0; i < N_UP; ++i) { conv_free(w.ups[i]); conv_free(w.source_downs[i]); }
+    for (int i = 0; i < 5; ++i) conv_free(w.f0c[i]);
+    auto free_rb = [](HiftConvs::RB& r) { for (int j = 0; j < N_DIL; ++j) { conv_free(r.c1[j]); conv_free(r.c2[j]); } };
+    for (int i = 0; i < N_UP; ++i) free_rb(w.src_rb[i]);
+    for (int i = 0; i < N_UP * N_RB; ++i) free_rb(w.rb[i]);
+}
+
+// ---- weight loading ---------------------------------------------------------------
+static int load_wn_conv(fy_hift* h, const Weights& W, const std::string& p, ConvW& cw, int Cout, int Cin, int KW, bool direct, bool mfma, hipStream_t st) {
+    const float* g = W.get(p + ".parametrizations.weight.original0", {Cout, 1, 1});
+    const float* v = W.get(p + ".parametrizations.weight.original1", {Cout, Cin, KW});
+    const float* b = W.get(p + ".bias", {Cout});
+    if (!g || !v || !b) return FY_ERR_WEIGHT;
+    if (mfma && (Cout % 32 != 0 || Cin % 4 != 0)) { mfma = false; direct = true; }
+    return conv_pack(cw, v, g, b, Cout, Cin, KW, 1, direct, mfma, st);
+}
+
+static int dev_copy(DevPool& pool, float** dst, const float* src, size_t n, hipStream_t st) {
+    FY_TRY(pool.alloc(dst, n));
+    HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return FY_OK;
+}
+
+static int load_rb(fy_hift* h, const Weights& W, const std::string& p, HiftConvs::RB& rb, int ch, int k, hipStream_t st) {
+    for (int j = 0; j < N_DIL; ++j) {
+        FY_TRY(load_wn_conv(h, W, p + ".convs1." + std::to_string(j), rb.c1[j], ch, ch, k, true, true, st));
+        FY_TRY(load_wn_conv(h, W, p + ".convs2." + std::to_string(j), rb.c2[j], ch, ch, k, true, true, st));
+        const float* a1 = W.get(p + ".activations1." + std::to_string(j) + ".alpha", {ch});
+        const float* a2 = W.get(p + ".activations2." + std::to_string(j) + ".alpha", {ch});
+        if (!a1 || !a2) return FY_ERR_WEIGHT;
+        FY_TRY(dev_copy(h->wpool, &rb.a1[j], a1, ch, st));
+        FY_TRY(dev_copy(h->wpool, &rb.a2[j], a2, ch, st));
+    }
+    return FY_OK;
+}
+
+extern "C" int fy_hift_create(fy_hift** out, const fy_hift_config* cfg, const fy_tensor* weights, int32_t n_weights,
+                              int32_t max_batch, int32_t max_frames, void* stream) {
+    FY_CHECK(out && max_batch >= 1 && max_frames >= 1, FY_ERR_ARG, "fy_hift_create: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    fy_hift* h = new fy_hift();
+    if (cfg) h->cfg = *cfg; else fy_hift_default_config(&h->cfg);
+    const fy_hift_config& c = h->cfg;
+    h->max_batch = max_batch; h->max_frames = max_frames;
+    h->up_total = c.hop * c.ups[0] * c.ups[1] * c.ups[2];
+    h->stft_per_frame = h->up_total / c.hop;
+    Weights W;
+    int rc = W.init(weights, n_weights);
+    auto fail = [&](int code) { delete h; return code; };
+    if (rc) return fail(rc);
+    if (c.n_fft != 16 || c.hop != 4) { fy_set_error("fy_hift_create: only n_fft 16 / hop 4 is built"); return fail(FY_ERR_ARG); }
+#define TRYC(e) do { int _r = (e); if (_r) return fail(_r); } while (0)
+    TRYC(load_wn_conv(h, W, "conv_pre", h->w.conv_pre, c.base, c.mel, c.pre_look_right + 1, true, true, st));
+    TRYC(load_wn_conv(h, W, "conv_post", h->w.conv_post, c.n_fft + 2, h->C(N_UP - 1), 7, true, false, st));
+    for (int i = 0; i < N_UP; ++i) {
+        TRYC(load_wn_conv(h, W, "ups." + std::to_string(i), h->w.ups[i], h->C(i), c.base >> i, c.up_k[i], true, true, st));
+        int k, s;
+        source_down_shape(c, i, &k, &s);
+        const float* v = W.get("source_downs." + std::to_string(i) + ".weight", {h->C(i), c.n_fft + 2, k});
+        const float* b = W.get("source_downs." + std::to_string(i) + ".bias", {h->C(i)});
+        if (!v || !b) return fail(FY_ERR_WEIGHT);
+        TRYC(conv_pack(h->w.source_downs[i], v, nullptr, b, h->C(i), c.n_fft + 2, k, 1, true, false, st));
+        TRYC(load_rb(h, W, "source_resblocks." + std::to_string(i), h->w.src_rb[i], h->C(i), c.src_rb_k[i], st));
+        for (int j = 0; j < N_RB; ++j)
+            TRYC(load_rb(h, W, "resblocks." + std::to_string(i * N_RB + j), h->w.rb[i * N_RB + j], h->C(i), c.rb_k[j], st));
+    }
+    TRYC(load_wn_conv(h, W, "f0_predictor.condnet.0", h->w.f0c[0], c.f0_ch, c.mel, 4, true, false, st));
+    for (int i = 1; i < 5; ++i)
+        TRYC(load_wn_conv(h, W, "f0_predictor.condnet." + std::to_string(2 * i), h->w.f0c[i], c.f0_ch, c.f0_ch, 3, true, false, st));
+    {
+        const float* cw = W.get("f0_predictor.classifier.weight", {1, c.f0_ch});
+        const float* cb = W.get("f0_predictor.classifier.bias", {1});
+        const float* lw = W.get("m_source.l_linear.weight", {1, c.harmonics + 1});
+        const float* lb = W.get("m_source.l_linear.bias", {1});
+        if (!cw || !cb || !lw || !lb) return fail(FY_ERR_WEIGHT);
+        TRYC(dev_copy(h->wpool, &h->cls_w, cw, c.f0_ch, st));
+        TRYC(dev_copy(h->wpool, &h->cls_b, cb, 1, st));
+        TRYC(dev_copy(h->wpool, &h->lin_w, lw, c.harmonics + 1, st));
+        TRYC(dev_copy(h->wpool, &h->lin_b, lb, 1, st));
+    }
+    // activations
+    const size_t B = max_batch, F = max_frames;
+    TRYC(h->pool.alloc(&h->mel_cl, B * F * c.mel));
+    TRYC(h->pool.alloc(&h->f0a, B * F * c.f0_ch));
+    TRYC(h->pool.alloc(&h->f0b, B * F * c.f0_ch));
+    TRYC(h->pool.alloc(&h->f0, B * F));
+    TRYC(h->pool.alloc(&h->rad_phase, B * F * (c.harmonics + 1)));
+    TRYC(h->pool.alloc(&h->source, B * F * h->up_total));
+    const size_t T = F * h->stft_per_frame + 1;
+    TRYC(h->pool.alloc(&h->s_stft, B * T * (c.n_fft + 2)));
+    TRYC(h->pool.alloc(&h->x_pre, B * F * c.base));
+    TRYC(h->pool.alloc(&h->post, B * T * (c.n_fft + 2)));
+    for (int i = 0; i < N_UP; ++i) {
+        size_t n = B * (size_t)h->L(i, (int)F) * h->C(i);
+        TRYC(h->pool.alloc(&h->x[i], n));
+        TRYC(h->pool.alloc(&h->xs[i], n));
+        TRYC(h->pool.alloc(&h->r[i], n));
+        TRYC(h->pool.alloc(&h->xt[i], n));
+        TRYC(h->pool.alloc(&h->si[i], n));
+    }
+    TRYC(h->pool.alloc(&h->lens, 6 * B));
+#undef TRYC
+    if (hipStreamSynchronize(st) != hipSuccess) { fy_set_error("fy_hift_create: stream sync failed"); return fail(FY_ERR_HIP); }
+    *out = h;
+    return FY_OK;
+}
+
+extern "C" void fy_hift_destroy(fy_hift* h) { delete h; }
+
+// ---- small kernels --------------------------------------------------------------
+// f0 = |Linear(f0_ch -> 1)(h)|, f0_predictor.py:102-103.  One wave per (b, frame).
+__global__ void f0_classifier_k(const float* __restrict__ hin, const float* __restrict__ w, const float* __restrict__ bias,
+                                float* __restrict__ f0, const int* __restrict__ frames, int Fmax, int ch) {
+    int b = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= frames[b]) return;
+    const float* row = hin + ((long)b * Fmax + t) * ch;
+    float s = 0.f;
+    for (int c = lane; c < ch; c += 64) s = fmaf(row[c], w[c], s);
+    s = wave_sum(s);
+    if (lane == 0) f0[(long)b * Fmax + t] = fabsf(s + bias[0]);
+}
+
+// SineGen2._f02sine per frame (generator.py:233-258, eval + causal): one thread per (b, harmonic) walks the
+// frames in order.  rad = (f0*(h+1)/sr) % 1; the x(1/480) linear down-sampling of the x480 nearest-repeated
+// signal returns the frame's own value (source index 480 i + 239.5, both neighbours inside frame i, so
+// rand_ini - added to sample 0 only - never enters); torch.cumsum on CPU accumulates fp32 data in double
+// and rounds each prefix to fp32; phase = ((cum*2)*pi)*480 in fp32; value = sin(phase) * sine_amp.
+__global__ void sine_phase_k(const float* __restrict__ f0, float* __restrict__ sines, const int* __restrict__ frames,
+                             int Fmax, int H1, float sr, float amp, float up) {
+    int b = blockIdx.x, hm = threadIdx.x;
+    if (hm >= H1) return;
+    int n = frames[b];
+    double cum = 0.0;
+    const float mult = (float)(hm + 1);
+    for (int t = 0; t < n; ++t) {
+        float fn = f0[(long)b * Fmax + t] * mult;
+        float q = fn / sr;
+        float rad = q - floorf(q);                  // torch '%' on floats: result takes the divisor's sign; q >= 0 here
+        float ds = 0.5f * rad + 0.5f * rad;
+        cum += (double)ds;
+        float ph = (float)cum;
+        ph = ph * 2.0f;
+        ph = ph * 3.14159265358979323846f;
+        ph = ph * up;
+        sines[((long)b * Fmax + t) * H1 + hm] = sinf(ph) * amp;
+    }
+}
+
+// SineGen2.forward :303-316 + SourceModuleHnNSF.forward :367-368, per sample.
+__global__ void source_k(const float* __restrict__ f0, const float* __restrict__ sines, const float* __restrict__ noise,
+                         const float* __restrict__ lw, const float* __restrict__ lb, float* __restrict__ src,
+                         const int* __restrict__ frames, int Fmax, int H1, int up, float thr, float sigma, float amp) {
+    int b = blockIdx.y;
+    long n = blockIdx.x * 256L + threadIdx.x;
+    long S = (long)frames[b] * up;
+    if (n >= S) return;
+    int t = (int)(n / up);
+    float f = f0[(long)b * Fmax + t];
+    float uv = f > thr ? 1.f : 0.f;
+    float namp = uv * sigma + ((1.f - uv) * amp) / 3.f;
+    float acc = lb[0];
+    for (int hm = 0; hm < H1; ++hm) {
+        float sw = sines[((long)b * Fmax + t) * H1 + hm] * uv + namp * noise[n * H1 + hm];
+        acc = fmaf(sw, lw[hm], acc);
+    }
+    src[(long)b * Fmax * up + n] = tanhf(acc);
+}
+
+__constant__ float c_cos16[16], c_sin16[16], c_hann16[16];
+
+// torch.stft(n_fft 16, hop 4, periodic hann, center + reflect), generator.py:491-497 -> (B, T, 18) = [re(9), im(9)]
+__global__ void stft16_k(const float* __restrict__ src, float* __restrict__ out, const int* __restrict__ frames, int Fmax, int up, int spf) {
+    int b = blockIdx.y;
+    int tt = blockIdx.x * 256 + threadIdx.x;
+    int S = frames[b] * up;
+    int T = frames[b] * spf + 1;
+    if (tt >= T) return;
+    const float* s = src + (long)b * Fmax * up;
+    float fr[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        int i = tt * 4 + n - 8;
+        if (i < 0) i = -i;
+        if (i >= S) i = 2 * (S - 1) - i;
+        fr[n] = s[i] * c_hann16[n];
+    }
+    float* o = out + ((long)b * (Fmax * spf + 1) + tt) * 18;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        float re = 0.f, im = 0.f;
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            int m = (k * n) & 15;
+            re = fmaf(fr[n], c_cos16[m], re);
+            im = fmaf(fr[n], -c_sin16[m], im);
+        }
+        o[k] = re;
+        o[9 + k] = im;
+    }
+}
+
+// generator.py:704-705 + _istft :499-502: conv_post output (B, T, 18) -> complex spectrum (in place layout)
+__global__ void spec_k(const float* __restrict__ post, float* __restrict__ spec, const int* __restrict__ frames, int Fmax, int spf) {
+    int b = blockIdx.y;
+    long i = blockIdx.x * 256L + threadIdx.x;
+    long T = (long)frames[b] * spf + 1;
+    if (i >= T * 9) return;
+    long t = i / 9;
+    int k = (int)(i % 9);
+    const float* p = post + ((long)b * (Fmax * spf + 1) + t) * 18;
+    float mag = fminf(expf(p[k]), 100.f);
+    float ph = sinf(p[9 + k]);
+    float* o = spec + ((long)b * (Fmax * spf + 1) + t) * 18;
+    o[k] = mag * cosf(ph);
+    o[9 + k] = mag * sinf(ph);
+}
+
+// torch.istft(center=True) + clamp, generator.py:503-505, 710: one thread per output sample.
+__global__ void istft16_k(const float* __restrict__ spec, float* __restrict__ wav, const int* __restrict__ frames, int Fmax, int up, int spf, float limit) {
+    int b = blockIdx.y;
+    long n = blockIdx.x * 256L + threadIdx.x;
+    long S = (long)frames[b] * up;
+    if (n >= S) return;
+    int T = frames[b] * spf + 1;
+    int m = (int)n + 8;                       // index in the un-trimmed overlap-add buffer
+    int t_hi = min(m / 4, T - 1);
+    int t_lo = max((m - 15 + 3) / 4, 0);
+    float y = 0.f, env = 0.f;
+    for (int t = t_lo; t <= t_hi; ++t) {
+        int j = m - 4 * t;                    // 0..15
+        const float* sp = spec + ((long)b * (Fmax * spf + 1) + t) * 18;
+        float v = sp[0] + ((j & 1) ? -sp[8] : sp[8]);      // DC + Nyquist (imaginary parts drop out)
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            int q = (k * j) & 15;
+            v += 2.f * (sp[k] * c_cos16[q] - sp[9 + k] * c_sin16[q]);
+        }
+        float w = c_hann16[j];
+        y += (v * (1.f / 16.f)) * w;
+        env += w * w;
+    }
+    y = y / env;
+    wav[(long)b * Fmax * up + n] = fminf(fmaxf(y, -limit), limit);
+}
+
+static bool g_tables_ready = false;
+static int init_tables() {
+    if (g_tables_ready) return FY_OK;
+    float c[16], s[16], w[16];
+    for (int i = 0; i < 16; ++i) {
+        c[i] = (float)cos(2.0 * M_PI * i / 16.0);
+        s[i] = (float)sin(2.0 * M_PI * i / 16.0);
+        w[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / 16.0));
+    }
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_cos16), c, sizeof(c)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_sin16), s, sizeof(s)));
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hann16), w, sizeof(w)));
+    g_tables_ready = true;
+    return FY_OK;
+}
+
+// ---- orchestration -----------------------------------------------------------------
+static int set_lens(fy_hift* h, const int32_t* frames, int B, int Fmax, hipStream_t st) {
+    FY_CHECK(h && frames && B >= 1 && B <= h->max_batch && Fmax >= 1 && Fmax <= h->max_frames, FY_ERR_ARG,
+             "hift: batch %d / frames %d outside the handle's limits (%d, %d)", B, Fmax, h ? h->max_batch : 0, h ? h->max_frames : 0);
+    std::vector<int> v(6 * h->max_batch, 0);
+    for (int b = 0; b < B; ++b) {
+        int F = frames[b];
+        FY_CHECK(F >= 1 && F <= Fmax, FY_ERR_ARG, "hift: frames[%d] = %d outside [1, %d]", b, F, Fmax);
+        int mb = h->max_batch;
+        v[0 * mb + b] = F;
+        v[1 * mb + b] = F * h->cfg.ups[0];
+        v[2 * mb + b] = F * h->cfg.ups[0] * h->cfg.ups[1];
+        v[3 * mb + b] = F * h->stft_per_frame;          // stage-2 conv rows before the reflect pad
+        v[4 * mb + b] = F * h->stft_per_frame + 1;
+        v[5 * mb + b] = F * h->up_total;
+    }
+    HIP_TRY(hipMemcpyAsync(h->lens, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));       // v goes out of scope
+    h->B = B; h->Fmax = Fmax;
+    return init_tables();
+}
+
+static ConvDesc base_desc(int B) {
+    ConvDesc d;
+    memset(&d, 0, sizeof(d));
+    d.B = B; d.dil = 1; d.stride = 1; d.up = 1; d.groups = 1; d.out_scale = 1.f;
+    return d;
+}
+
+static int run_conv(const ConvDesc& d, const ConvW& w, uint32_t flags, hipStream_t st) {
+    if (!(flags & FY_DIRECT) && w.w_mfma) return conv1d_bf16_mfma(d, w, (flags & FY_PRECISE) != 0, st);
+    return conv1d_f32_direct(d, w, st);
+}
+
+static int hift_f0(fy_hift* h, int B, int Fmax, hipStream_t st) {
+    const fy_hift_config& c = h->cfg;
+    const int* lF = h->lens;
+    // condnet[0]: k4, 3 frames of right look-ahead; then 4x k3 left-causal; ELU after each (f0_predictor.py:74-90)
+    const float* in = h->mel_cl;
+    int in_ld = c.mel;
+    float* bufs[2] = {h->f0a, h->f0b};
+    for (int i = 0; i < 5; ++i) {
+        ConvDesc d = base_desc(B);
+        d.x = in; d.x_bs = (long)Fmax * in_ld; d.x_ld = in_ld; d.L_in = Fmax; d.in_len = lF;
+        d.y = bufs[i & 1]; d.y_bs = (long)Fmax * c.f0_ch; d.y_ld = c.f0_ch; d.L_out = Fmax; d.out_len = lF;
+        d.Cin = i == 0 ? c.mel : c.f0_ch; d.Cout = c.f0_ch; d.KW = h->w.f0c[i].KW;
+        d.pad_left = i == 0 ? 0 : (d.KW - 1);
+        d.bias = h->w.f0c[i].bias; d.post_act = ACT_ELU;
+        FY_TRY(conv1d_f32_direct(d, h->w.f0c[i], st));
+        in = bufs[i & 1]; in_ld = c.f0_ch;
+    }
+    hipLaunchKernelGGL(f0_classifier_k, dim3(cdiv(Fmax, 4), B), dim3(256), 0, st, in, h->cls_w, h->cls_b, h->f0, lF, Fmax, c.f0_ch);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+static int hift_source(fy_hift* h, const float* f0, int B, int Fmax, const float* rand_ini, const float* sine_noise, hipStream_t st) {
+    const fy_hift_config& c = h->cfg;
+    (void)rand_ini;   // provably without effect on the output (see sine_phase_k); kept in the ABI for fidelity
+    const int H1 = c.harmonics + 1;
+    hipLaunchKernelGGL(sine_phase_k, dim3(B), dim3(64), 0, st, f0, h->rad_phase, h->lens, Fmax, H1, (float)c.sampling_rate,
+                       c.nsf_alpha, (float)h->up_total);
+    hipLaunchKernelGGL(source_k, dim3(cdiv(Fmax * h->up_total, 256), B), dim3(256), 0, st, f0, h->rad_phase, sine_noise, h->lin_w,
+                       h->lin_b, h->source, h->lens, Fmax, H1, h->up_total, c.voiced_thr, c.nsf_sigma, c.nsf_alpha);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+// one ResBlock (generator.py:110-117): x_in -> out.  `work` holds the running x between iterations, `xt` the
+// inner activation.  final_dst/final_scale/final_acc: where the last iteration's x goes ((conv2 + x)*scale).
+static int run_resblock(fy_hift* h, const HiftConvs::RB& rb, const float* x_in, float* work, float* xt, float* final_dst,
+                        float final_scale, int final_acc, int B, int Lmax, const int* len, int C, uint32_t flags, hipStream_t st) {
+    const fy_hift_config& c = h->cfg;
+    const long bs = (long)Lmax * C;
+    for (int j = 0; j < N_DIL; ++j) {
+        const float* cur = j == 0 ? x_in : work;
+        ConvDesc d = base_desc(B);
+        d.x = cur; d.x_bs = bs; d.x_ld = C; d.L_in = Lmax; d.in_len = len;
+        d.y = xt; d.y_bs = bs; d.y_ld = C; d.L_out = Lmax; d.out_len = len;
+        d.Cin = C; d.Cout = C; d.KW = rb.c1[j].KW; d.dil = c.rb_d[j]; d.pad_left = (d.KW - 1) * d.dil;
+        d.pre_act = ACT_SNAKE; d.alpha = rb.a1[j]; d.bias = rb.c1[j].bias;
+        FY_TRY(run_conv(d, rb.c1[j], flags, st));
+        ConvDesc e = base_desc(B);
+        e.x = xt; e.x_bs = bs; e.x_ld = C; e.L_in = Lmax; e.in_len = len;
+        e.L_out = Lmax; e.out_len = len;
+        e.Cin = C; e.Cout = C; e.KW = rb.c2[j].KW; e.dil = 1; e.pad_left = e.KW - 1;
+        e.pre_act = ACT_SNAKE; e.alpha = rb.a2[j]; e.bias = rb.c2[j].bias;
+        e.add_resid = 1; e.resid = cur; e.r_bs = bs; e.r_ld = C;
+        if (j == N_DIL - 1) {
+            e.y = final_dst; e.out_scale = final_scale; e.accumulate = final_acc;
+        } else {
+            e.y = work;
+        }
+        e.y_bs = bs; e.y_ld = C;
+        FY_TRY(run_conv(e, rb.c2[j], flags, st));
+    }
+    return FY_OK;
+}
+
+static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, hipStream_t st) {
+    const fy_hift_config& c = h->cfg;
+    const int mb = h->max_batch;
+    const int spf = h->stft_per_frame, up = h->up_total;
+    const int Tmax = Fmax * spf + 1;
+    hipLaunchKernelGGL(stft16_k, dim3(cdiv(Tmax, 256), B), dim3(256), 0, st, h->source, h->s_stft, h->lens, Fmax, up, spf);
+    {   // conv_pre: k5, 4 frames of right look-ahead (generator.py:621-623, 675)
+        ConvDesc d = base_desc(B);
+        d.x = h->mel_cl; d.x_bs = (long)Fmax * c.mel; d.x_ld = c.mel; d.L_in = Fmax; d.in_len = h->lens;
+        d.y = h->x_pre; d.y_bs = (long)Fmax * c.base; d.y_ld = c.base; d.L_out = Fmax; d.out_len = h->lens;
+        d.Cin = c.mel; d.Cout = c.base; d.KW = c.pre_look_right + 1; d.pad_left = 0; d.bias = h->w.conv_pre.bias;
+        FY_TRY(run_conv(d, h->w.conv_pre, flags, st));
+    }
+    const float* xin = h->x_pre;
+    int Cin = c.base, Lin_max = Fmax;
+    const int* len_in = h->lens;
+    for (int i = 0; i < N_UP; ++i) {
+        const int C = h->C(i);
+        const int Lmax = h->L(i, Fmax);
+        const int* len = h->lens + (i == N_UP - 1 ? 4 : i + 1) * mb;          // rows of this stage's tensors
+        const int* len_conv = h->lens + (i + 1) * mb;                           // rows the up-conv itself produces
+        const long bs = (long)Lmax * C;
+        {   // source branch: si = source_resblocks[i](source_downs[i](s_stft)), generator.py:690-691
+            int k, s;
+            source_down_shape(c, i, &k, &s);
+            ConvDesc d = base_desc(B);
+            d.x = h->s_stft; d.x_bs = (long)Tmax * 18; d.x_ld = 18; d.L_in = Tmax; d.in_len = h->lens + 4 * mb;
+            d.y = h->r[i]; d.y_bs = bs; d.y_ld = C; d.L_out = Lmax; d.out_len = len;
+            d.Cin = 18; d.Cout = C; d.KW = k; d.stride = s; d.pad_left = s == 1 ? 0 : s - 1; d.bias = h->w.source_downs[i].bias;
+            FY_TRY(conv1d_f32_direct(d, h->w.source_downs[i], st));
+            FY_TRY(run_resblock(h, h->w.src_rb[i], h->r[i], h->r[i], h->xt[i], h->si[i], 1.f, 0, B, Lmax, len, C, flags, st));
+        }
+        {   // x = ups[i](leaky_relu(x)) [reflect pad on the last stage] + si, generator.py:683-692
+            ConvDesc d = base_desc(B);
+            d.x = xin; d.x_bs = (long)Lin_max * Cin; d.x_ld = Cin; d.L_in = Lin_max; d.in_len = len_in;
+            d.y = h->x[i]; d.y_bs = bs; d.y_ld = C; d.L_out = Lin_max * c.ups[i]; d.out_len = len_conv;
+            d.Cin = Cin; d.Cout = C; d.KW = c.up_k[i]; d.up = c.ups[i]; d.pad_left = c.up_k[i] - 1;
+            d.pre_act = ACT_LEAKY; d.pre_slope = c.lrelu; d.bias = h->w.ups[i].bias;
+            d.add_resid = 1; d.resid = h->si[i]; d.r_bs = bs; d.r_ld = C;
+            d.reflect1 = i == N_UP - 1;
+            FY_TRY(run_conv(d, h->w.ups[i], flags, st));
+        }
+        for (int j = 0; j < N_RB; ++j)   // x = mean_j resblocks[3i+j](x), generator.py:694-700
+            FY_TRY(run_resblock(h, h->w.rb[i * N_RB + j], h->x[i], h->r[i], h->xt[i], h->xs[i], 1.f / N_RB, j > 0, B, Lmax, len, C, flags, st));
+        xin = h->xs[i]; Cin = C; Lin_max = Lmax; len_in = len;
+    }
+    {   // conv_post on leaky_relu(x, 0.01), generator.py:702-703
+        ConvDesc d = base_desc(B);
+        d.x = xin; d.x_bs = (long)Lin_max * Cin; d.x_ld = Cin; d.L_in = Lin_max; d.in_len = len_in;
+        d.y = h->post; d.y_bs = (long)Tmax * 18; d.y_ld = 18; d.L_out = Tmax; d.out_len = len_in;
+        d.Cin = Cin; d.Cout = 18; d.KW = 7; d.pad_left = 6; d.pre_act = ACT_LEAKY; d.pre_slope = 0.01f; d.bias = h->w.conv_post.bias;
+        FY_TRY(conv1d_f32_direct(d, h->w.conv_post, st));
+    }
+    // the spectrum overwrites s_stft (no longer needed)
+    hipLaunchKernelGGL(spec_k, dim3(cdiv(Tmax * 9, 256), B), dim3(256), 0, st, h->post, h->s_stft, h->lens, Fmax, spf);
+    hipLaunchKernelGGL(istft16_k, dim3(cdiv(Fmax * up, 256), B), dim3(256), 0, st, h->s_stft, wav, h->lens, Fmax, up, spf, c.audio_limit);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+static int load_mel(fy_hift* h, const float* mel, int B, int Fmax, hipStream_t st) {
+    return transpose_bcl_to_blc(mel, h->mel_cl, B, h->cfg.mel, Fmax, (long)h->cfg.mel * Fmax, (long)Fmax * h->cfg.mel, h->cfg.mel, st);
+}
+
+extern "C" int fy_hift_infer(fy_hift* h, const float* mel, const int32_t* frames, int32_t B, int32_t Fmax, const float* rand_ini,
+                             const float* sine_noise, float* wav, float* source, uint32_t flags, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(h && mel && sine_noise && wav, FY_ERR_ARG, "fy_hift_infer: null argument");
+    FY_TRY(set_lens(h, frames, B, Fmax, st));
+    FY_TRY(load_mel(h, mel, B, Fmax, st));
+    FY_TRY(hift_f0(h, B, Fmax, st));
+    FY_TRY(hift_source(h, h->f0, B, Fmax, rand_ini, sine_noise, st));
+    if (source) HIP_TRY(hipMemcpyAsync(source, h->source, (size_t)B * Fmax * h->up_total * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return hift_decode(h, B, Fmax, wav, flags, st);
+}
+
+extern "C" int fy_hift_f0(fy_hift* h, const float* mel, const int32_t* frames, int32_t B, int32_t Fmax, float* f0, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(h && mel && f0, FY_ERR_ARG, "fy_hift_f0: null argument");
+    FY_TRY(set_lens(h, frames, B, Fmax, st));
+    FY_TRY(load_mel(h, mel, B, Fmax, st));
+    FY_TRY(hift_f0(h, B, Fmax, st));
+    HIP_TRY(hipMemcpyAsync(f0, h->f0, (size_t)B * Fmax * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return FY_OK;
+}
+
+extern "C" int fy_hift_source(fy_hift* h, const float* f0, const int32_t* frames, int32_t B, int32_t Fmax, const float* rand_ini,
+                              const float* sine_noise, float* source, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(h && f0 && sine_noise && source, FY_ERR_ARG, "fy_hift_source: null argument");
+    FY_TRY(set_lens(h, frames, B, Fmax, st));
+    HIP_TRY(hipMemcpyAsync(h->f0, f0, (size_t)B * Fmax * sizeof(float), hipMemcpyDeviceToDevice, st));
+    FY_TRY(hift_source(h, h->f0, B, Fmax, rand_ini, sine_noise, st));
+    HIP_TRY(hipMemcpyAsync(source, h->source, (size_t)B * Fmax * h->up_total * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return FY_OK;
+}
+
+extern "C" int fy_hift_decode(fy_hift* h, const float* mel, const float* source, const int32_t* frames, int32_t B, int32_t Fmax,
+                              float* wav, uint32_t flags, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(h && mel && source && wav, FY_ERR_ARG, "fy_hift_decode: null argument");
+    FY_TRY(set_lens(h, frames, B, Fmax, st));
+    FY_TRY(load_mel(h, mel, B, Fmax, st));
+    HIP_TRY(hipMemcpyAsync(h->source, source, (size_t)B * Fmax * h->up_total * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return hift_decode(h, B, Fmax, wav, flags, st);
+}
+
+extern "C" int fy_hift_tap(fy_hift* h, const char* name, float* dst, int64_t* rows, int64_t* cols, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(h && name && dst && rows && cols && h->B > 0, FY_ERR_ARG, "fy_hift_tap: null argument or no call made yet");
+    const int F = h->Fmax, spf = h->stft_per_frame;
+    const float* src = nullptr;
+    std::string n = name;
+    if (n == "f0") { src = h->f0; *rows = F; *cols = 1; }
+    else if (n == "source") { src = h->source; *rows = (int64_t)F * h->up_total; *cols = 1; }
+    else if (n == "conv_pre") { src = h->x_pre; *rows = F; *cols = h->cfg.base; }
+    else if (n == "conv_post") { src = h->post; *rows = F * spf + 1; *cols = 18; }
+    else if (n.size() == 5 && n.substr(0, 4) == "fuse" && n[4] >= '0' && n[4] < '0' + N_UP) {
+        int i = n[4] - '0'; src = h->x[i]; *rows = h->L(i, F); *cols = h->C(i);
+    } else if (n.size() == 6 && n.substr(0, 5) == "stage" && n[5] >= '0' && n[5] < '0' + N_UP) {
+        int i = n[5] - '0'; src = h->xs[i]; *rows = h->L(i, F); *cols = h->C(i);
+    } else {
+        fy_set_error("fy_hift_tap: unknown tap '%s'", name);
+        return FY_ERR_ARG;
+    }
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)h->B * (*rows) * (*cols) * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return FY_OK;
+}
+
+extern "C" int fy_hift_resblock(fy_hift* h, int32_t index, const float* x, float* y, int32_t B, int32_t L, uint32_t flags, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(h && x && y && index >= 0 && index < N_UP * N_RB && B >= 1 && L >= 1, FY_ERR_ARG, "fy_hift_resblock: bad argument");
+    const int stage = index / N_RB, C = h->C(stage);
+    FY_CHECK(B <= h->max_batch && L <= h->L(stage, h->max_frames), FY_ERR_ARG,
+             "fy_hift_resblock: (B %d, L %d) exceeds the handle's workspace (%d, %d)", B, L, h->max_batch, h->L(stage, h->max_frames));
+    return run_resblock(h, h->w.rb[index], x, h->r[stage], h->xt[stage], y, 1.f, 0, B, L, nullptr, C, flags, st);
+}

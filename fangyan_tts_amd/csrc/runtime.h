@@ -1,0 +1,42 @@
+// Host-side plumbing shared by the three engines: error string, named-weight
+// lookup with shape checks, device buffers, layout transposes.
+#pragma once
+#include "common.h"
+#include "../../include/fy_cosy3.h"
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+struct Weights {
+    std::unordered_map<std::string, const fy_tensor*> m;
+    int init(const fy_tensor* w, int n);
+    // device pointer of `name` after checking its shape; nullptr (+ error set) when absent or mis-shaped
+    const float* get(const std::string& name, std::initializer_list<long> shape) const;
+    bool has(const std::string& name) const { return m.count(name) != 0; }
+};
+
+// owns device allocations, frees them in the destructor
+struct DevPool {
+    std::vector<void*> ptrs;
+    size_t bytes = 0;
+    template <typename T>
+    int alloc(T** p, size_t n) {
+        void* q = nullptr;
+        hipError_t e = hipMalloc(&q, n * sizeof(T) + 256);
+        if (e != hipSuccess) {
+            fy_set_error("hipMalloc(%zu B) failed: %s", n * sizeof(T), hipGetErrorString(e));
+            return FY_ERR_HIP;
+        }
+        ptrs.push_back(q);
+        bytes += n * sizeof(T);
+        *p = (T*)q;
+        return FY_OK;
+    }
+    ~DevPool() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+};
+
+// (B, C, L) -> (B, L, C) with per-batch strides in elements
+int transpose_bcl_to_blc(const float* src, float* dst, int B, int C, int L, long src_bs, long dst_bs, int dst_ld, hipStream_t st);
+int transpose_blc_to_bcl(const float* src, float* dst, int B, int C, int L, long src_bs, int src_ld, long dst_bs, hipStream_t st);

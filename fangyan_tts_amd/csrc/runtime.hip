@@ -1,0 +1,89 @@
+#include "runtime.h"
+#include <stdarg.h>
+
+static thread_local char g_err[1024] = "";
+
+void fy_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* fy_last_error(void) { return g_err; }
+extern "C" int fy_version(void) { return 100; }
+
+int Weights::init(const fy_tensor* w, int n) {
+    FY_CHECK(w != nullptr && n > 0, FY_ERR_ARG, "no weights given");
+    for (int i = 0; i < n; ++i) {
+        FY_CHECK(w[i].name && w[i].data && w[i].ndim >= 1 && w[i].ndim <= 4, FY_ERR_WEIGHT, "weight #%d is malformed", i);
+        m[w[i].name] = &w[i];
+    }
+    return FY_OK;
+}
+
+const float* Weights::get(const std::string& name, std::initializer_list<long> shape) const {
+    auto it = m.find(name);
+    if (it == m.end()) {
+        fy_set_error("missing weight '%s'", name.c_str());
+        return nullptr;
+    }
+    const fy_tensor* t = it->second;
+    bool ok = (size_t)t->ndim == shape.size();
+    int i = 0;
+    for (long s : shape) {
+        if (ok && t->shape[i] != s) ok = false;
+        ++i;
+    }
+    if (!ok) {
+        std::string want, got;
+        for (long s : shape) want += std::to_string(s) + ",";
+        for (int k = 0; k < t->ndim; ++k) got += std::to_string((long)t->shape[k]) + ",";
+        fy_set_error("weight '%s' has shape (%s), expected (%s)", name.c_str(), got.c_str(), want.c_str());
+        return nullptr;
+    }
+    return (const float*)t->data;
+}
+
+// 32x32 LDS-tiled transposes
+__global__ void tr_bcl_blc_k(const float* __restrict__ src, float* __restrict__ dst, int C, int L, long src_bs, long dst_bs, int dst_ld) {
+    __shared__ float tile[32][33];
+    int b = blockIdx.z, c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, l = l0 + tx;
+        tile[i][tx] = (c < C && l < L) ? src[b * src_bs + (long)c * L + l] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int l = l0 + i, c = c0 + tx;
+        if (c < C && l < L) dst[b * dst_bs + (long)l * dst_ld + c] = tile[tx][i];
+    }
+}
+__global__ void tr_blc_bcl_k(const float* __restrict__ src, float* __restrict__ dst, int C, int L, long src_bs, int src_ld, long dst_bs) {
+    __shared__ float tile[32][33];
+    int b = blockIdx.z, c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
+    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        int l = l0 + i, c = c0 + tx;
+        tile[i][tx] = (c < C && l < L) ? src[b * src_bs + (long)l * src_ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, l = l0 + tx;
+        if (c < C && l < L) dst[b * dst_bs + (long)c * L + l] = tile[tx][i];
+    }
+}
+
+int transpose_bcl_to_blc(const float* src, float* dst, int B, int C, int L, long src_bs, long dst_bs, int dst_ld, hipStream_t st) {
+    dim3 grid(cdiv(L, 32), cdiv(C, 32), B);
+    hipLaunchKernelGGL(tr_bcl_blc_k, grid, dim3(256), 0, st, src, dst, C, L, src_bs, dst_bs, dst_ld);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+int transpose_blc_to_bcl(const float* src, float* dst, int B, int C, int L, long src_bs, int src_ld, long dst_bs, hipStream_t st) {
+    dim3 grid(cdiv(L, 32), cdiv(C, 32), B);
+    hipLaunchKernelGGL(tr_blc_bcl_k, grid, dim3(256), 0, st, src, dst, C, L, src_bs, src_ld, dst_bs);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}

@@ -1,0 +1,212 @@
+"""Counter-based synthetic weights, noise buffers and inputs.
+
+No pretrained CosyVoice3 checkpoint is reachable offline, so every parity and
+benchmark run uses weights drawn from this generator (SURVEY §8c "Synthetic
+weights").  Each element is a pure function of (tensor name, flat index), so
+
+* the reference modules (tests/golden/mint_goldens.py), the CPU oracle
+  (oracle/) and the HIP engine are filled with identical values without
+  shipping 859 M parameters;
+* any prefix / row subset of a huge tensor (SineGen2's 7.2 M x 9 noise table,
+  the 151 936-row text embedding) can be produced without the rest.
+
+Matrix-shaped weights are rounded to bf16-representable fp32 values: the engine
+stores them as bf16 without loss, so engine-vs-oracle differences measure the
+kernels, not a quantisation step.
+"""
+from __future__ import annotations
+
+import re
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_C1 = np.uint64(0xBF58476D1CE4E5B9)
+_C2 = np.uint64(0x94D049BB133111EB)
+
+
+def name_seed(name: str) -> int:
+    """FNV-1a 64-bit of the tensor name."""
+    h = 0xCBF29CE484222325
+    for b in name.encode():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _hash(seed: int, idx: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser of seed + (idx+1)*golden; idx uint64 array."""
+    with np.errstate(over="ignore"):
+        z = (idx + np.uint64(1)) * _GOLD + np.uint64(seed)
+        z = (z ^ (z >> np.uint64(30))) * _C1
+        z = (z ^ (z >> np.uint64(27))) * _C2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def u01(name: str, n: int, start: int = 0) -> np.ndarray:
+    """n uniform [0,1) float64 values for flat indices start..start+n."""
+    seed = name_seed(name)
+    out = np.empty(n, dtype=np.float64)
+    step = 1 << 24
+    for s in range(0, n, step):
+        e = min(n, s + step)
+        idx = np.arange(start + s, start + e, dtype=np.uint64)
+        out[s:e] = (_hash(seed, idx) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+    return out
+
+
+def uniform(name: str, shape, lo: float, hi: float, start: int = 0) -> np.ndarray:
+    n = int(np.prod(shape))
+    return (lo + (hi - lo) * u01(name, n, start)).astype(np.float32).reshape(shape)
+
+
+def normal(name: str, shape, mean: float = 0.0, std: float = 1.0, start: int = 0) -> np.ndarray:
+    """Box-Muller on the (2i, 2i+1) uniforms of element i."""
+    n = int(np.prod(shape))
+    u = u01(name, 2 * n, 2 * start).reshape(n, 2)
+    r = np.sqrt(-2.0 * np.log(1.0 - u[:, 0]))
+    z = r * np.cos(2.0 * np.pi * u[:, 1])
+    return (mean + std * z).astype(np.float32).reshape(shape)
+
+
+def randint(name: str, shape, lo: int, hi: int) -> np.ndarray:
+    """Integers in [lo, hi)."""
+    n = int(np.prod(shape))
+    return (lo + np.floor(u01(name, n) * (hi - lo))).astype(np.int32).reshape(shape)
+
+
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """Round fp32 to the nearest bf16-representable fp32 (ties to even)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32).reshape(x.shape)
+
+
+def to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """fp32 -> uint16 bf16 bit patterns (round to nearest even)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)
+    return r.astype(np.uint16).reshape(x.shape)
+
+
+# (regex, kind, param).  First match wins.  kinds:
+#   w      : uniform(-a, a), a = gain*sqrt(3/fan_in), rounded to bf16
+#   b      : uniform(-p, p)
+#   one    : 1 + uniform(-p, p)
+#   range  : uniform(p[0], p[1])
+#   emb    : uniform(-p, p) rounded to bf16
+_RULES = [
+    # ---- HiFT
+    (r"activations[12]\.\d+\.alpha$", "range", (0.5, 1.5)),
+    (r"^conv_post\.bias$", "postbias", None),
+    (r"^conv_post\..*original1$", "w", 0.5),
+    (r"^(source_)?resblocks\.\d+\.convs2\..*original1$", "w", 0.35),
+    (r"^(source_)?resblocks\.\d+\.convs1\..*original1$", "w", 0.7),
+    (r"^source_downs\.\d+\.weight$", "w", 1.0),
+    (r"^f0_predictor\.classifier\.weight$", "wf32", 60.0),
+    (r"^f0_predictor\.classifier\.bias$", "range", (40.0, 60.0)),
+    (r"^f0_predictor\..*original1$", "wf32", 1.3),
+    (r"^m_source\.l_linear\.weight$", "wf32", 3.0),
+    # ---- LLM
+    (r"^llm_decoder\.weight$", "w", 4.0),
+    (r"embed_tokens\.weight$|^speech_embedding\.weight$|lm_head\.weight$", "emb", 0.2),
+    (r"layernorm\.weight$|model\.norm\.weight$", "one", 0.1),
+    # ---- flow
+    (r"^input_embedding\.weight$", "emb", 1.0),
+    (r"attn_norm\.linear\.weight$|norm_out\.linear\.weight$", "w", 1.0),
+    (r"proj_out\.weight$", "w", 1.0),
+    # ---- generic
+    (r"original1$|\.weight$", "w", 1.0),
+    (r"\.bias$", "b", 0.05),
+]
+_RULES = [(re.compile(p), k, a) for p, k, a in _RULES]
+
+
+def tensor(name: str, shape: Tuple[int, ...], rows: Optional[Iterable[int]] = None) -> np.ndarray:
+    """Synthetic fp32 value of a named weight (not for weight-norm g, see state_dict)."""
+    shape = tuple(int(s) for s in shape)
+    for rx, kind, arg in _RULES:
+        if rx.search(name):
+            break
+    else:
+        raise KeyError(f"no synth rule for {name}")
+    if rows is not None:
+        rows = list(rows)
+        row_elems = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        parts = [_gen(name, kind, arg, (1,) + shape[1:], shape, start=r * row_elems) for r in rows]
+        return np.concatenate(parts, axis=0)
+    return _gen(name, kind, arg, shape, shape, 0)
+
+
+def _gen(name, kind, arg, shape, full_shape, start):
+    if kind in ("w", "wf32"):
+        fan_in = int(np.prod(full_shape[1:])) if len(full_shape) > 1 else full_shape[0]
+        a = float(arg) * np.sqrt(3.0 / fan_in)
+        x = uniform(name, shape, -a, a, start)
+        return bf16_round(x) if kind == "w" else x
+    if kind == "emb":
+        return bf16_round(uniform(name, shape, -arg, arg, start))
+    if kind == "b":
+        return uniform(name, shape, -arg, arg, start)
+    if kind == "one":
+        return (1.0 + uniform(name, shape, -arg, arg, start)).astype(np.float32)
+    if kind == "range":
+        return uniform(name, shape, arg[0], arg[1], start)
+    if kind == "postbias":
+        # magnitude channels (first n_fft/2+1) biased negative so exp() stays
+        # well below the 1e2 clip and the waveform is not pinned at +-0.99
+        x = uniform(name, shape, -0.05, 0.05, start)
+        half = full_shape[0] // 2
+        x[:half] -= 1.0
+        return x
+    raise ValueError(kind)
+
+
+def weight_norm_g(v: np.ndarray) -> np.ndarray:
+    """g for a weight-normed conv: per-output-channel ||v|| times a power of two
+    (1 or 1/2), so g*v/||v|| is v or v/2 up to one rounding: the folded weight
+    stays bf16-representable and the fold is still exercised."""
+    co = v.shape[0]
+    nrm = np.sqrt((v.astype(np.float64).reshape(co, -1) ** 2).sum(axis=1))
+    s = np.where(np.arange(co) % 3 == 0, 0.5, 1.0)
+    return (nrm * s).astype(np.float32).reshape(co, 1, 1)
+
+
+def state_dict(manifest: Dict[str, Tuple[int, ...]], skip: Iterable[str] = ()) -> Dict[str, np.ndarray]:
+    """All tensors of a manifest (spec.py) as fp32 numpy arrays."""
+    skip = tuple(skip)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in manifest.items():
+        if any(s in name for s in skip):
+            continue
+        if name.endswith("parametrizations.weight.original0"):
+            continue
+        out[name] = tensor(name, shape)
+    for name in manifest:
+        if name.endswith("parametrizations.weight.original0") and not any(s in name for s in skip):
+            out[name] = weight_norm_g(out[name[:-1] + "1"])
+    if "llm.model.lm_head.weight" in out and "llm.model.model.embed_tokens.weight" in out:
+        out["llm.model.lm_head.weight"] = out["llm.model.model.embed_tokens.weight"]  # tied
+    return out
+
+
+# ---- non-checkpointed noise buffers of the reference -------
+
+def flow_rand_noise(n_frames: int, mel: int = 80, total: int = 15000) -> np.ndarray:
+    """Stand-in for CausalConditionalCFM.rand_noise[:, :, :n_frames] (1, mel, n).
+    Laid out (mel, total) so a frame prefix of each row is a contiguous index range."""
+    rows = [normal("flow.rand_noise", (n_frames,), start=c * total) for c in range(mel)]
+    return np.stack(rows, axis=0)[None]
+
+
+def hift_rand_ini(harm: int = 9) -> np.ndarray:
+    x = uniform("hift.rand_ini", (1, harm), 0.0, 1.0)
+    x[:, 0] = 0.0
+    return x
+
+
+def hift_sine_noise(n_samples: int, harm: int = 9) -> np.ndarray:
+    """Stand-in for SineGen2.sine_waves[:, :n_samples] (1, n, harm), uniform [0,1)."""
+    return uniform("hift.sine_waves", (1, n_samples, harm), 0.0, 1.0)

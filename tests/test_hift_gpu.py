@@ -1,0 +1,155 @@
+"""GPU parity: the HIP HiFT vocoder (through the C ABI) against the CPU oracle
+and the golden fixture minted from the reference.
+
+Modes and their stated tolerances (absolute, on tensors whose scale is O(1);
+wav is in [-0.99, 0.99] with |wav| ~ 0.1 for the synthetic weights):
+  FY_DIRECT   exact fp32 VALU convolutions                 -> 2e-4
+  FY_PRECISE  bf16 MFMA with split (hi+lo) activations     -> 2e-3
+  default     bf16 MFMA, activations rounded to bf16       -> 3e-2 on taps, 1e-2 on wav
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from _digest import check
+from fangyan_tts_amd import synth
+from fangyan_tts_amd.spec import HiftCfg
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+OUT = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+
+
+def note(key, value):
+    os.makedirs(OUT, exist_ok=True)
+    p = os.path.join(OUT, "parity_hift.json")
+    d = json.load(open(p)) if os.path.exists(p) else {}
+    d[key] = value
+    json.dump(d, open(p, "w"), indent=1, sort_keys=True)
+
+
+def maxerr(a, b):
+    return float((a.detach().cpu().float() - b.detach().cpu().float()).abs().max())
+
+
+@pytest.fixture(scope="module")
+def env():
+    from fangyan_tts_amd.hift import HiftEngine
+    from oracle import hift as ohift
+    cfg = HiftCfg()
+    sd = synth.state_dict(cfg.manifest())
+    dev = torch.device("cuda:0")
+    eng = HiftEngine({k: torch.from_numpy(v).to(dev) for k, v in sd.items()}, cfg, max_batch=4, max_frames=64)
+    P = ohift.prepare(sd)
+    ri = torch.from_numpy(synth.hift_rand_ini())
+    sn = torch.from_numpy(synth.hift_sine_noise(64 * 480))
+    return dict(cfg=cfg, eng=eng, P=P, o=ohift, dev=dev, ri=ri, sn=sn, ri_d=ri.to(dev), sn_d=sn.to(dev).contiguous())
+
+
+def mel_of(Fr):
+    return torch.from_numpy(synth.uniform(f"in.hift.mel.{Fr}", (1, 80, Fr), 0.0, 1.0))
+
+
+def test_f0_and_source(env):
+    o, eng, cfg = env["o"], env["eng"], env["cfg"]
+    mel = mel_of(30)
+    with torch.no_grad():
+        f0_ref = o.f0_predictor(mel, env["P"])
+        s_ref = o.sine_source(f0_ref, env["P"], cfg, env["ri"], env["sn"][:, : 30 * 480])
+    f0 = eng.f0(mel.to(env["dev"]))
+    e = maxerr(f0, f0_ref)
+    note("f0_maxerr", e)
+    assert e < 2e-3 * float(f0_ref.abs().max())
+    # source from the oracle's own f0: isolates the sine generator
+    s = eng.source(f0_ref.to(env["dev"]), env["ri_d"], env["sn_d"])
+    e = maxerr(s, s_ref)
+    note("source_maxerr_same_f0", e)
+    assert e < 2e-4
+
+
+@pytest.mark.parametrize("mode,flags,tol_tap,tol_wav", [
+    ("direct", 2, 2e-4, 5e-5), ("precise", 1, 2e-3, 5e-4), ("bf16", 0, 3e-2, 1e-2)])
+def test_decode_against_oracle(env, mode, flags, tol_tap, tol_wav):
+    o, eng, cfg = env["o"], env["eng"], env["cfg"]
+    Fr = 30
+    mel = mel_of(Fr)
+    with torch.no_grad():
+        f0 = o.f0_predictor(mel, env["P"])
+        s = o.sine_source(f0, env["P"], cfg, env["ri"], env["sn"][:, : Fr * 480])
+        taps = o.decode_taps(mel, s, env["P"], cfg)
+    wav = eng.decode(mel.to(env["dev"]), s.to(env["dev"]), flags=flags)
+    for k in ("conv_pre", "fuse0", "stage0", "fuse1", "stage1", "fuse2", "stage2", "conv_post"):
+        got = eng.tap(k, 1, Fr)
+        e = maxerr(got, taps[k])
+        note(f"decode.{mode}.{k}", e)
+        assert e < tol_tap * max(1.0, float(taps[k].abs().max())), (k, e)
+    e = maxerr(wav, taps["wav"])
+    note(f"decode.{mode}.wav", e)
+    assert e < tol_wav
+
+
+def test_golden_reference_wav(env):
+    """The fixture minted from the reference's CausalHiFTGenerator (F=30, full size)."""
+    p = os.path.join(G, "hift_full.npz")
+    if not os.path.exists(p):
+        pytest.skip("hift_full.npz not minted")
+    f = np.load(p)
+    eng = env["eng"]
+    wav, src = eng.inference(mel_of(30).to(env["dev"]), env["ri_d"], env["sn_d"], flags=2, want_source=True)
+    check(src.cpu(), f, "F30.source", 1e-3, 5e-3)
+    check(wav.cpu(), f, "F30.wav", 1e-3, 2e-3)
+    np.testing.assert_allclose(wav.cpu().numpy(), f["F30.wav_full"], atol=2e-3)
+    wav2, _ = eng.inference(mel_of(30).to(env["dev"]), env["ri_d"], env["sn_d"], flags=0)
+    np.testing.assert_allclose(wav2.cpu().numpy(), f["F30.wav_full"], atol=1.5e-2)
+    note("golden.wav_bf16_maxerr", float(np.abs(wav2.cpu().numpy() - f["F30.wav_full"]).max()))
+
+
+@pytest.mark.parametrize("index", range(9))
+def test_resblock(env, index):
+    o, eng, cfg = env["o"], env["eng"], env["cfg"]
+    i, j = divmod(index, 3)
+    x = torch.from_numpy(synth.normal(f"in.hift.rb.{i}.{j}", (1, cfg.stage_ch(i), 200)))
+    with torch.no_grad():
+        ref = o.resblock(x, env["P"], f"resblocks.{index}", cfg.rb_d)
+    f = np.load(os.path.join(G, "hift_full.npz")) if os.path.exists(os.path.join(G, "hift_full.npz")) else None
+    for mode, flags, tol in (("direct", 2, 2e-4), ("precise", 1, 2e-3), ("bf16", 0, 4e-2)):
+        y = eng.resblock(index, x.to(env["dev"]), flags)
+        e = maxerr(y, ref)
+        note(f"resblock{index}.{mode}", e)
+        assert e < tol * max(1.0, float(ref.abs().max())), (mode, e)
+        if f is not None and mode == "direct":
+            check(y.cpu(), f, f"rb{index}", 1e-3, 1e-3)
+
+
+def test_ragged_batch_equals_solo(env):
+    """Utterances of different length in one batch match their solo runs (causal net, per-utterance lengths)."""
+    eng, dev = env["eng"], env["dev"]
+    frames = [30, 17, 24]
+    mels = [mel_of(30)[:, :, :f] for f in frames]
+    batch = torch.zeros(3, 80, 30)
+    for b, m in enumerate(mels):
+        batch[b, :, : frames[b]] = m[0]
+    # garbage beyond each utterance's length must not leak in
+    batch[1, :, 17:] = 7.0
+    wav, _ = eng.inference(batch.to(dev), env["ri_d"], env["sn_d"], frames=frames, flags=0)
+    for b, m in enumerate(mels):
+        solo, _ = eng.inference(m.contiguous().to(dev), env["ri_d"], env["sn_d"], flags=0)
+        n = frames[b] * 480
+        assert torch.equal(wav[b, :n], solo[0, :n]), b
+        assert float(wav[b, n:].abs().max()) == 0.0 if n < wav.shape[1] else True
+
+
+def test_full_inference_against_oracle(env):
+    o, eng, cfg = env["o"], env["eng"], env["cfg"]
+    Fr = 24
+    mel = mel_of(30)[:, :, :Fr].contiguous()
+    with torch.no_grad():
+        ref, _ = o.inference(mel, env["P"], cfg, env["ri"], env["sn"][:, : Fr * 480])
+    for mode, flags, tol in (("direct", 2, 2e-3), ("bf16", 0, 1.5e-2)):
+        wav, _ = eng.inference(mel.to(env["dev"]), env["ri_d"], env["sn_d"], flags=flags)
+        e = maxerr(wav, ref)
+        note(f"inference.{mode}.wav", e)
+        assert e < tol
