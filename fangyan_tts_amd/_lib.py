@@ -26,8 +26,23 @@ class HiftConfig(C.Structure):
                 ("lrelu", C.c_float), ("audio_limit", C.c_float), ("pre_look_right", C.c_int32), ("f0_ch", C.c_int32)]
 
 
+class FlowConfig(C.Structure):
+    _fields_ = [("mel", C.c_int32), ("spk_in", C.c_int32), ("vocab", C.c_int32), ("pre_ch", C.c_int32),
+                ("pre_lookahead", C.c_int32), ("dim", C.c_int32), ("depth", C.c_int32), ("heads", C.c_int32),
+                ("head_dim", C.c_int32), ("ff_mult", C.c_int32), ("conv_pos_k", C.c_int32), ("conv_pos_groups", C.c_int32),
+                ("n_timesteps", C.c_int32), ("cfg_rate", C.c_float), ("static_chunk", C.c_int32), ("t_span", C.c_float * 33)]
+
+
+class LlmConfig(C.Structure):
+    _fields_ = [("hidden", C.c_int32), ("layers", C.c_int32), ("q_heads", C.c_int32), ("kv_heads", C.c_int32),
+                ("head_dim", C.c_int32), ("inter", C.c_int32), ("vocab", C.c_int32), ("speech_tokens", C.c_int32),
+                ("rms_eps", C.c_float), ("rope_theta", C.c_float)]
+
+
 FY_PRECISE = 1
 FY_DIRECT = 2
+FY_STREAMING = 4
+FY_LLM_KEEP_LOGP = 4
 
 _lib = None
 
@@ -63,6 +78,20 @@ def _declare(L):
     L.fy_hift_decode.argtypes = [vp, f32p, f32p, i32p, i32, i32, f32p, u32, vp]
     L.fy_hift_tap.argtypes = [vp, C.c_char_p, f32p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), vp]
     L.fy_hift_resblock.argtypes = [vp, i32, f32p, f32p, i32, i32, u32, vp]
+    L.fy_flow_default_config.argtypes = [C.POINTER(FlowConfig)]
+    L.fy_flow_default_config.restype = None
+    L.fy_flow_create.argtypes = [C.POINTER(vp), C.POINTER(FlowConfig), C.POINTER(FyTensor), i32, i32, i32, vp]
+    L.fy_flow_destroy.argtypes = [vp]
+    L.fy_flow_destroy.restype = None
+    L.fy_flow_infer.argtypes = [vp, vp, i32, i32p, vp, i32, i32p, f32p, i32, i32p, f32p, f32p, i32, i32, f32p, i32, u32, vp]
+    L.fy_dit_estimator.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, f32p, i32, i32, u32, vp]
+    L.fy_llm_default_config.argtypes = [C.POINTER(LlmConfig)]
+    L.fy_llm_default_config.restype = None
+    L.fy_llm_create.argtypes = [C.POINTER(vp), C.POINTER(LlmConfig), C.POINTER(FyTensor), i32, i32, i32, vp]
+    L.fy_llm_destroy.argtypes = [vp]
+    L.fy_llm_destroy.restype = None
+    L.fy_llm_generate.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, i32, vp, i32, vp, vp, u32, vp]
+    L.fy_llm_logp.argtypes = [vp, i32, f32p, vp]
 
 
 def tensor_table(weights):

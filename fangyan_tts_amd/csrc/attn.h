@@ -1,0 +1,11 @@
+#pragma once
+#include "common.h"
+
+// qkv: bf16 [nseq*Tmax][3*H*64] laid out [q | k | v]; out: bf16 [nseq*Tmax][H*64]; seq_len: device int[nseq].
+// chunk > 0 adds the streaming block-causal mask key < (query/chunk + 1)*chunk.
+int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st);
+
+// fp32 GQA attention over the KV cache, head_dim 64.  q: [R][q_ld]; K/V cache: [seq][Hk][max_ctx][64];
+// row r attends positions 0..row_pos[r] of sequence row_seq[r].
+int llm_attention(const float* q, int q_ld, const float* Kc, const float* Vc, const int* row_seq, const int* row_pos, float* out,
+                  int o_ld, int R, int Hq, int Hk, int max_ctx, hipStream_t st);

@@ -1,0 +1,517 @@
+// Flow-matching acoustic decoder engine: CausalMaskedDiffWithDiT.inference ->
+// CausalConditionalCFM.solve_euler -> DiT.forward for a batch of ragged utterances.
+// Reference: CosyVoice/cosyvoice/flow/flow.py:358-403, flow/flow_matching.py:71-124,
+// flow/DiT/dit.py:145-176, flow/DiT/modules.py (cited per kernel).
+//
+// Layout: the DiT works on nseq = 2*B sequences (row 2b = conditional, 2b+1 = CFG branch with
+// mu = spks = cond = 0), each padded to Tmax rows: row (s*Tmax + t).  The residual stream h is
+// fp32; GEMM operands are bf16 with fp32 MFMA accumulation; the adaLN-zero modulation depends on
+// the Euler step only, so all (step, block) vectors are computed once at create.
+#include "attn.h"
+#include "conv.h"
+#include "gemm.h"
+#include "runtime.h"
+#include <math.h>
+
+struct FlowBlockW {
+    bf16_t *wqkv, *wo, *w1, *w2, *wmod;
+    float *bqkv, *bo, *b1, *b2, *bmod;
+};
+
+struct fy_flow {
+    fy_flow_config cfg;
+    int max_batch = 0, Tmax = 0, Nmax = 0;       // Tmax mel frames, Nmax = Tmax/2 tokens
+    DevPool pool;
+    // front
+    float *emb_w, *spk_w, *spk_b;
+    ConvW pre1, pre2, pos1, pos2;
+    // estimator
+    bf16_t *w_in, *w_out, *w_t0, *w_t2, *w_fin;
+    float *b_in, *b_out, *b_t0, *b_t2, *b_fin;
+    std::vector<FlowBlockW> blk;
+    float* mod = nullptr;      // [(n_steps+1)][depth][6*dim]   (slot n_steps = scratch for fy_dit_estimator)
+    float* fin = nullptr;      // [(n_steps+1)][2*dim]
+    float2* rope = nullptr;    // [Tmax][head_dim/2] (cos, sin)
+    std::vector<float> t_of_step, dt_of_step;
+    // activations
+    int *tok_all, *seq_len, *blen;     // blen: [4][max_batch] = n_all tokens, T, pmel, (unused)
+    float *emb, *pre_a, *mu_tok, *spks, *x, *mu, *cond, *h, *c1, *v, *temb, *tsil, *gpart;
+    bf16_t *a_in, *xn, *qkv, *ao, *ff;
+    ~fy_flow() { conv_free(pre1); conv_free(pre2); conv_free(pos1); conv_free(pos2); }
+};
+
+extern "C" void fy_flow_default_config(fy_flow_config* c) {
+    memset(c, 0, sizeof(*c));
+    c->mel = 80; c->spk_in = 192; c->vocab = 6561; c->pre_ch = 1024; c->pre_lookahead = 3;
+    c->dim = 1024; c->depth = 22; c->heads = 16; c->head_dim = 64; c->ff_mult = 2;
+    c->conv_pos_k = 31; c->conv_pos_groups = 16; c->n_timesteps = 10; c->cfg_rate = 0.7f; c->static_chunk = 50;
+    // t_span = 1 - cos(linspace(0,1,n+1) * pi/2)  (flow_matching.py:223-225); callers that need the
+    // reference's exact fp32 values overwrite it with torch's
+    for (int i = 0; i <= 10; ++i) c->t_span[i] = (float)(1.0 - cos(((double)i / 10.0) * 0.5 * M_PI));
+}
+
+// ---- small kernels ------------------------------------------------------------------------------
+// F.normalize(embedding, dim=1) then Linear(192 -> 80): flow.py:371-372.  One block per utterance.
+__global__ void spk_k(const float* __restrict__ e, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out, int nin, int nout) {
+    __shared__ float sh[256];
+    __shared__ float xs[512];
+    int bb = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nin; i += 256) { float v = e[(long)bb * nin + i]; xs[i] = v; s += v * v; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+    float nrm = fmaxf(sqrtf(sh[0]), 1e-12f);
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        float a = 0.f;
+        for (int i = 0; i < nin; ++i) a = fmaf(xs[i] / nrm, w[(long)o * nin + i], a);
+        out[(long)bb * nout + o] = a + b[o];
+    }
+}
+
+// concat[prompt_token, token] and the embedding gather, flow.py:375-377 (mask is all ones inside n_all)
+__global__ void tok_embed_k(const int* __restrict__ ptok, int p_ld, const int* __restrict__ tok, int t_ld, const int* __restrict__ n_prompt,
+                            const int* __restrict__ n_all, int* __restrict__ tok_all, const float* __restrict__ W, float* __restrict__ emb,
+                            int Nmax, int C, int vocab) {
+    int b = blockIdx.y, i = blockIdx.x;
+    if (i >= n_all[b]) return;
+    int P = n_prompt[b];
+    int id = i < P ? ptok[(long)b * p_ld + i] : tok[(long)b * t_ld + (i - P)];
+    id = max(id, 0);
+    id = min(id, vocab - 1);
+    if (threadIdx.x == 0) tok_all[(long)b * Nmax + i] = id;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) emb[((long)b * Nmax + i) * C + c] = W[(long)id * C + c];
+}
+
+// mu = repeat_interleave(h, 2), cond = [prompt_feat; 0], x0 = rand_noise[:, :T]   (flow.py:383-390, flow_matching.py:220)
+__global__ void flow_setup_k(const float* __restrict__ mu_tok, const float* __restrict__ pfeat, long pf_bs, const float* __restrict__ noise, int noise_ld,
+                             const int* __restrict__ T, const int* __restrict__ pmel, float* __restrict__ mu, float* __restrict__ cond,
+                             float* __restrict__ x, int Tmax, int Nmax, int C) {
+    int b = blockIdx.y, t = blockIdx.x, c = threadIdx.x;
+    if (t >= T[b] || c >= C) return;
+    long o = ((long)b * Tmax + t) * C + c;
+    mu[o] = mu_tok[((long)b * Nmax + (t >> 1)) * C + c];
+    cond[o] = t < pmel[b] ? pfeat[(long)b * pf_bs + (long)t * C + c] : 0.f;
+    x[o] = noise[(long)c * noise_ld + t];
+}
+
+// InputEmbedding concat [x, cond, mu, spks] (dit.py:91-96) for the conditional row and [x, 0, 0, 0]
+// for the CFG row (flow_matching.py:95-101), as the bf16 A operand of the input projection.
+__global__ void dit_assemble_k(const float* __restrict__ x, const float* __restrict__ cond, const float* __restrict__ mu, const float* __restrict__ spks,
+                               const int* __restrict__ T, bf16_t* __restrict__ a, int Tmax, int C) {
+    int s = blockIdx.y, t = blockIdx.x, b = s >> 1, cfg = s & 1;
+    int i = threadIdx.x;                     // 0 .. 4C
+    if (i >= 4 * C) return;
+    float v = 0.f;
+    if (t < T[b]) {
+        long o = ((long)b * Tmax + t) * C;
+        int part = i / C, c = i % C;
+        if (part == 0) v = x[o + c];
+        else if (!cfg) v = part == 1 ? cond[o + c] : (part == 2 ? mu[o + c] : spks[(long)b * C + c]);
+    }
+    a[((long)s * Tmax + t) * 4 * C + i] = f32_to_bf16(v);
+}
+
+// LayerNorm(eps 1e-6, no affine) * (1 + scale) + shift -> bf16 (modules.py:238-243, 524, 262-264). One wave per row.
+__global__ __launch_bounds__(256) void ln_mod_k(const float* __restrict__ h, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                bf16_t* __restrict__ out, int M, int D) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float* p = h + (long)row * D;
+    float v[16];
+    const int per = D / 64;                   // <= 16
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { v[i] = i < per ? p[lane + 64 * i] : 0.f; s += v[i]; }
+    float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { float d = i < per ? v[i] - mean : 0.f; q += d * d; }
+    float rstd = rsqrtf(wave_sum(q) / D + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < per) {
+            int c = lane + 64 * i;
+            out[(long)row * D + c] = f32_to_bf16((v[i] - mean) * rstd * (1.f + scale[c]) + shift[c]);
+        }
+    }
+}
+
+// x-transformers apply_rotary_pos_emb on the un-split q and k (modules.py:368-373): only channels
+// 0..rot-1 (= head 0) rotate, in interleaved pairs.  qkv bf16 [M][3*inner], in place.
+__global__ void dit_rope_k(bf16_t* __restrict__ qkv, const float2* __restrict__ tab, const int* __restrict__ seq_len, int Tmax, int inner, int half) {
+    int s = blockIdx.y, t = blockIdx.x, i = threadIdx.x;      // i < 2*half: q pairs then k pairs
+    if (t >= seq_len[s] || i >= 2 * half) return;
+    int which = i / half, pr = i % half;
+    bf16_t* p = qkv + ((long)s * Tmax + t) * 3 * inner + which * inner + 2 * pr;
+    float a = bf16_to_f32(p[0]), b = bf16_to_f32(p[1]);
+    float2 cs = tab[(long)t * half + pr];
+    p[0] = f32_to_bf16(a * cs.x - b * cs.y);
+    p[1] = f32_to_bf16(b * cs.x + a * cs.y);
+}
+
+// CFG mix and Euler update, flow_matching.py:114-118
+__global__ void euler_k(float* __restrict__ x, const float* __restrict__ v, const int* __restrict__ T, int Tmax, int C, float dt, float cfg) {
+    int b = blockIdx.y, t = blockIdx.x, c = threadIdx.x;
+    if (t >= T[b] || c >= C) return;
+    float vc = v[((long)(2 * b) * Tmax + t) * C + c], vu = v[((long)(2 * b + 1) * Tmax + t) * C + c];
+    float d = (1.0f + cfg) * vc - cfg * vu;
+    long o = ((long)b * Tmax + t) * C + c;
+    x[o] = x[o] + dt * d;
+}
+
+__global__ void silu_k(const float* __restrict__ a, float* __restrict__ o, long n) {
+    long i = blockIdx.x * 256L + threadIdx.x;
+    if (i < n) o[i] = act_silu(a[i]);
+}
+
+// ---- create -----------------------------------------------------------------------------------------
+static int to_bf16(fy_flow* f, const float* src, size_t n, bf16_t** dst, hipStream_t st) {
+    FY_TRY(f->pool.alloc(dst, n));
+    return cast_f32_bf16(src, *dst, n, st);
+}
+static int copy_f32(fy_flow* f, const float* src, size_t n, float** dst, hipStream_t st) {
+    FY_TRY(f->pool.alloc(dst, n));
+    HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return FY_OK;
+}
+
+// modulation vectors of one set of timesteps: slot0.. (rows = n), see modules.py:606-616, 239-241, 260-261
+static int compute_mod(fy_flow* f, const float* t_host, int n, int slot0, hipStream_t st) {
+    const fy_flow_config& c = f->cfg;
+    const int D = c.dim;
+    std::vector<float> emb((size_t)n * 256);
+    const int half = 128;
+    const float k = logf(10000.f) / (half - 1);
+    for (int r = 0; r < n; ++r)
+        for (int i = 0; i < half; ++i) {
+            float fr = expf((float)i * -k);
+            float a = 1000.f * t_host[r] * fr;
+            emb[(size_t)r * 256 + i] = sinf(a);
+            emb[(size_t)r * 256 + half + i] = cosf(a);
+        }
+    float* d_emb = f->temb + (size_t)16 * D;       // scratch behind temb/tsil (allocated 16*D*3)
+    HIP_TRY(hipMemcpyAsync(d_emb, emb.data(), emb.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    GemvArgs a;
+    a.W = f->w_t0; a.x = d_emb; a.ldx = 256; a.R = n; a.N = D; a.K = 256; a.bias = f->b_t0; a.y = f->tsil; a.ldy = D;
+    FY_TRY(gemv_bf16w(a, st));
+    hipLaunchKernelGGL(silu_k, dim3(cdiv(n * D, 256)), dim3(256), 0, st, f->tsil, f->tsil, (long)n * D);
+    a.W = f->w_t2; a.x = f->tsil; a.ldx = D; a.K = D; a.bias = f->b_t2; a.y = f->temb;
+    FY_TRY(gemv_bf16w(a, st));
+    hipLaunchKernelGGL(silu_k, dim3(cdiv(n * D, 256)), dim3(256), 0, st, f->temb, f->tsil, (long)n * D);
+    for (int i = 0; i < c.depth; ++i) {
+        GemvArgs m;
+        m.W = f->blk[i].wmod; m.x = f->tsil; m.ldx = D; m.R = n; m.N = 6 * D; m.K = D; m.bias = f->blk[i].bmod;
+        m.y = f->mod + ((size_t)slot0 * c.depth + i) * 6 * D; m.ldy = c.depth * 6 * D;
+        FY_TRY(gemv_bf16w(m, st));
+    }
+    GemvArgs m;
+    m.W = f->w_fin; m.x = f->tsil; m.ldx = D; m.R = n; m.N = 2 * D; m.K = D; m.bias = f->b_fin;
+    m.y = f->fin + (size_t)slot0 * 2 * D; m.ldy = 2 * D;
+    FY_TRY(gemv_bf16w(m, st));
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy_tensor* weights, int32_t n_weights,
+                              int32_t max_batch, int32_t max_frames, void* stream) {
+    FY_CHECK(out && max_batch >= 1 && max_frames >= 2, FY_ERR_ARG, "fy_flow_create: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    fy_flow* f = new fy_flow();
+    if (cfg) f->cfg = *cfg; else fy_flow_default_config(&f->cfg);
+    const fy_flow_config& c = f->cfg;
+    auto fail = [&](int code) { delete f; return code; };
+    if (c.head_dim != 64 || c.dim % 256 != 0 || c.dim > 1024 || c.n_timesteps < 1 || c.n_timesteps > 32 || c.mel != 80 ||
+        c.heads * c.head_dim != c.dim || (c.dim / c.conv_pos_groups) % 4 != 0) {
+        fy_set_error("fy_flow_create: unsupported architecture (head_dim %d, dim %d, heads %d)", c.head_dim, c.dim, c.heads);
+        return fail(FY_ERR_ARG);
+    }
+    f->max_batch = max_batch;
+    f->Tmax = (max_frames + 1) & ~1;
+    f->Nmax = f->Tmax / 2;
+    Weights W;
+    int rc = W.init(weights, n_weights);
+    if (rc) return fail(rc);
+#define TRYC(e) do { int _r = (e); if (_r) return fail(_r); } while (0)
+#define GETW(var, name, ...) const float* var = W.get(name, {__VA_ARGS__}); if (!var) return fail(FY_ERR_WEIGHT)
+    const int D = c.dim, C = c.mel, inner = c.heads * c.head_dim, FF = D * c.ff_mult;
+    {
+        GETW(ew, "input_embedding.weight", c.vocab, C);
+        GETW(sw, "spk_embed_affine_layer.weight", C, c.spk_in);
+        GETW(sb, "spk_embed_affine_layer.bias", C);
+        TRYC(copy_f32(f, ew, (size_t)c.vocab * C, &f->emb_w, st));
+        TRYC(copy_f32(f, sw, (size_t)C * c.spk_in, &f->spk_w, st));
+        TRYC(copy_f32(f, sb, C, &f->spk_b, st));
+        GETW(p1w, "pre_lookahead_layer.conv1.weight", c.pre_ch, C, c.pre_lookahead + 1);
+        GETW(p1b, "pre_lookahead_layer.conv1.bias", c.pre_ch);
+        GETW(p2w, "pre_lookahead_layer.conv2.weight", C, c.pre_ch, 3);
+        GETW(p2b, "pre_lookahead_layer.conv2.bias", C);
+        TRYC(conv_pack(f->pre1, p1w, nullptr, p1b, c.pre_ch, C, c.pre_lookahead + 1, 1, true, false, st));
+        TRYC(conv_pack(f->pre2, p2w, nullptr, p2b, C, c.pre_ch, 3, 1, true, false, st));
+    }
+    const std::string E = "decoder.estimator.";
+    {
+        GETW(t0w, E + "time_embed.time_mlp.0.weight", D, 256);
+        GETW(t0b, E + "time_embed.time_mlp.0.bias", D);
+        GETW(t2w, E + "time_embed.time_mlp.2.weight", D, D);
+        GETW(t2b, E + "time_embed.time_mlp.2.bias", D);
+        GETW(iw, E + "input_embed.proj.weight", D, 4 * C);
+        GETW(ib, E + "input_embed.proj.bias", D);
+        GETW(ow, E + "proj_out.weight", C, D);
+        GETW(ob, E + "proj_out.bias", C);
+        GETW(fw, E + "norm_out.linear.weight", 2 * D, D);
+        GETW(fb, E + "norm_out.linear.bias", 2 * D);
+        TRYC(to_bf16(f, t0w, (size_t)D * 256, &f->w_t0, st)); TRYC(copy_f32(f, t0b, D, &f->b_t0, st));
+        TRYC(to_bf16(f, t2w, (size_t)D * D, &f->w_t2, st)); TRYC(copy_f32(f, t2b, D, &f->b_t2, st));
+        TRYC(to_bf16(f, iw, (size_t)D * 4 * C, &f->w_in, st)); TRYC(copy_f32(f, ib, D, &f->b_in, st));
+        TRYC(to_bf16(f, ow, (size_t)C * D, &f->w_out, st)); TRYC(copy_f32(f, ob, C, &f->b_out, st));
+        TRYC(to_bf16(f, fw, (size_t)2 * D * D, &f->w_fin, st)); TRYC(copy_f32(f, fb, 2 * D, &f->b_fin, st));
+        const int cg = D / c.conv_pos_groups;
+        GETW(c1w, E + "input_embed.conv_pos_embed.conv1.0.weight", D, cg, c.conv_pos_k);
+        GETW(c1b, E + "input_embed.conv_pos_embed.conv1.0.bias", D);
+        GETW(c2w, E + "input_embed.conv_pos_embed.conv2.0.weight", D, cg, c.conv_pos_k);
+        GETW(c2b, E + "input_embed.conv_pos_embed.conv2.0.bias", D);
+        const bool mf = cg % 32 == 0;
+        TRYC(conv_pack(f->pos1, c1w, nullptr, c1b, D, D, c.conv_pos_k, c.conv_pos_groups, true, mf, st));
+        TRYC(conv_pack(f->pos2, c2w, nullptr, c2b, D, D, c.conv_pos_k, c.conv_pos_groups, true, mf, st));
+    }
+    f->blk.resize(c.depth);
+    for (int i = 0; i < c.depth; ++i) {
+        const std::string b = E + "transformer_blocks." + std::to_string(i) + ".";
+        FlowBlockW& k = f->blk[i];
+        GETW(mw, b + "attn_norm.linear.weight", 6 * D, D);
+        GETW(mb, b + "attn_norm.linear.bias", 6 * D);
+        GETW(qw, b + "attn.to_q.weight", inner, D); GETW(qb, b + "attn.to_q.bias", inner);
+        GETW(kw, b + "attn.to_k.weight", inner, D); GETW(kb, b + "attn.to_k.bias", inner);
+        GETW(vw, b + "attn.to_v.weight", inner, D); GETW(vb, b + "attn.to_v.bias", inner);
+        GETW(ow, b + "attn.to_out.0.weight", D, inner); GETW(ob, b + "attn.to_out.0.bias", D);
+        GETW(f1w, b + "ff.ff.0.0.weight", FF, D); GETW(f1b, b + "ff.ff.0.0.bias", FF);
+        GETW(f2w, b + "ff.ff.2.weight", D, FF); GETW(f2b, b + "ff.ff.2.bias", D);
+        TRYC(to_bf16(f, mw, (size_t)6 * D * D, &k.wmod, st)); TRYC(copy_f32(f, mb, 6 * D, &k.bmod, st));
+        TRYC(f->pool.alloc(&k.wqkv, (size_t)3 * inner * D));
+        TRYC(f->pool.alloc(&k.bqkv, (size_t)3 * inner));
+        const float* ws[3] = {qw, kw, vw};
+        const float* bs[3] = {qb, kb, vb};
+        for (int j = 0; j < 3; ++j) {
+            TRYC(cast_f32_bf16(ws[j], k.wqkv + (size_t)j * inner * D, (size_t)inner * D, st));
+            if (hipMemcpyAsync(k.bqkv + (size_t)j * inner, bs[j], inner * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                fy_set_error("fy_flow_create: bias copy failed");
+                return fail(FY_ERR_HIP);
+            }
+        }
+        TRYC(to_bf16(f, ow, (size_t)D * inner, &k.wo, st)); TRYC(copy_f32(f, ob, D, &k.bo, st));
+        TRYC(to_bf16(f, f1w, (size_t)FF * D, &k.w1, st)); TRYC(copy_f32(f, f1b, FF, &k.b1, st));
+        TRYC(to_bf16(f, f2w, (size_t)D * FF, &k.w2, st)); TRYC(copy_f32(f, f2b, D, &k.b2, st));
+    }
+    // activations
+    const size_t B = max_batch, T = f->Tmax, N = f->Nmax, M = 2 * B * T;
+    TRYC(f->pool.alloc(&f->tok_all, B * N)); TRYC(f->pool.alloc(&f->seq_len, 2 * B)); TRYC(f->pool.alloc(&f->blen, 4 * B));
+    TRYC(f->pool.alloc(&f->emb, B * N * C)); TRYC(f->pool.alloc(&f->pre_a, B * N * c.pre_ch)); TRYC(f->pool.alloc(&f->mu_tok, B * N * C));
+    TRYC(f->pool.alloc(&f->spks, B * C)); TRYC(f->pool.alloc(&f->x, B * T * C)); TRYC(f->pool.alloc(&f->mu, B * T * C));
+    TRYC(f->pool.alloc(&f->cond, B * T * C)); TRYC(f->pool.alloc(&f->h, M * D)); TRYC(f->pool.alloc(&f->c1, M * D));
+    TRYC(f->pool.alloc(&f->v, M * C)); TRYC(f->pool.alloc(&f->temb, (size_t)16 * D * 3)); TRYC(f->pool.alloc(&f->tsil, (size_t)16 * D));
+    TRYC(f->pool.alloc(&f->a_in, M * 4 * C)); TRYC(f->pool.alloc(&f->xn, M * D)); TRYC(f->pool.alloc(&f->qkv, M * 3 * inner));
+    TRYC(f->pool.alloc(&f->ao, M * inner)); TRYC(f->pool.alloc(&f->ff, M * FF));
+    TRYC(f->pool.alloc(&f->mod, (size_t)(c.n_timesteps + 1) * c.depth * 6 * D));
+    TRYC(f->pool.alloc(&f->fin, (size_t)(c.n_timesteps + 1) * 2 * D));
+    TRYC(f->pool.alloc(&f->rope, T * (c.head_dim / 2)));
+    {
+        std::vector<float2> tab(T * (c.head_dim / 2));
+        for (size_t t = 0; t < T; ++t)
+            for (int i = 0; i < c.head_dim / 2; ++i) {
+                float inv = 1.0f / powf(10000.f, (float)(2 * i) / (float)c.head_dim);
+                float ang = (float)t * inv;
+                tab[t * (c.head_dim / 2) + i] = make_float2(cosf(ang), sinf(ang));
+            }
+        if (hipMemcpyAsync(f->rope, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            fy_set_error("fy_flow_create: rope table upload failed");
+            return fail(FY_ERR_HIP);
+        }
+    }
+    // Euler schedule with the reference's running accumulation (flow_matching.py:87-88, 118-122)
+    {
+        const int n = c.n_timesteps;
+        float t = c.t_span[0], dt = c.t_span[1] - c.t_span[0];
+        for (int step = 1; step <= n; ++step) {
+            f->t_of_step.push_back(t);
+            f->dt_of_step.push_back(dt);
+            t = t + dt;
+            if (step < n) dt = c.t_span[step + 1] - t;
+        }
+        for (int s0 = 0; s0 < n; s0 += 8) TRYC(compute_mod(f, f->t_of_step.data() + s0, std::min(8, n - s0), s0, st));
+    }
+#undef GETW
+#undef TRYC
+    if (hipStreamSynchronize(st) != hipSuccess) { fy_set_error("fy_flow_create: stream sync failed"); return fail(FY_ERR_HIP); }
+    *out = f;
+    return FY_OK;
+}
+
+extern "C" void fy_flow_destroy(fy_flow* f) { delete f; }
+
+// ---- estimator ----------------------------------------------------------------------------------------
+// One DiT.forward over nseq sequences whose bf16 input rows are in f->a_in; result rows (fp32, C wide) in f->v.
+static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming, uint32_t flags, hipStream_t st) {
+    const fy_flow_config& c = f->cfg;
+    const int D = c.dim, C = c.mel, inner = c.heads * c.head_dim, FF = D * c.ff_mult;
+    const int M = nseq * Tmax;
+    GemmEpi e;
+    e.bias = f->b_in; e.out = f->h; e.out_bf16 = 0; e.ldc = D;
+    FY_TRY(gemm_bf16(f->a_in, 4 * C, f->w_in, M, D, 4 * C, e, st));
+    {   // x = conv_pos_embed(x) + x, modules.py:129-144 (causal, grouped, Mish)
+        ConvDesc d;
+        memset(&d, 0, sizeof(d));
+        d.B = nseq; d.dil = 1; d.stride = 1; d.up = 1; d.groups = c.conv_pos_groups; d.out_scale = 1.f;
+        d.x = f->h; d.x_bs = (long)Tmax * D; d.x_ld = D; d.L_in = Tmax; d.in_len = f->seq_len;
+        d.y = f->c1; d.y_bs = (long)Tmax * D; d.y_ld = D; d.L_out = Tmax; d.out_len = f->seq_len;
+        d.Cin = D; d.Cout = D; d.KW = c.conv_pos_k; d.pad_left = c.conv_pos_k - 1; d.bias = f->pos1.bias; d.post_act = ACT_MISH;
+        const bool mf = f->pos1.w_mfma != nullptr && !(flags & FY_DIRECT);
+        FY_TRY(mf ? conv1d_bf16_mfma(d, f->pos1, (flags & FY_PRECISE) != 0, st) : conv1d_f32_direct(d, f->pos1, st));
+        d.x = f->c1; d.y = f->h; d.bias = f->pos2.bias;
+        d.add_resid = 1; d.resid = f->h; d.r_bs = (long)Tmax * D; d.r_ld = D;
+        FY_TRY(mf ? conv1d_bf16_mfma(d, f->pos2, (flags & FY_PRECISE) != 0, st) : conv1d_f32_direct(d, f->pos2, st));
+    }
+    const float* modbase = f->mod + (size_t)slot * c.depth * 6 * D;
+    for (int i = 0; i < c.depth; ++i) {
+        const FlowBlockW& k = f->blk[i];
+        const float* m = modbase + (size_t)i * 6 * D;       // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + D, m, f->xn, M, D);
+        GemmEpi q;
+        q.bias = k.bqkv; q.out = f->qkv; q.out_bf16 = 1; q.ldc = 3 * inner;
+        FY_TRY(gemm_bf16(f->xn, D, k.wqkv, M, 3 * inner, D, q, st));
+        hipLaunchKernelGGL(dit_rope_k, dim3(Tmax, nseq), dim3(64), 0, st, f->qkv, f->rope, f->seq_len, Tmax, inner, c.head_dim / 2);
+        FY_TRY(dit_attention(f->qkv, f->ao, f->seq_len, nseq, Tmax, c.heads, streaming ? c.static_chunk : 0, st));
+        GemmEpi o;
+        o.mode = EPI_GATE_RESID; o.bias = k.bo; o.resid = f->h; o.gate = m + 2 * D; o.ldc = D;
+        FY_TRY(gemm_bf16(f->ao, inner, k.wo, M, D, inner, o, st));
+        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + 4 * D, m + 3 * D, f->xn, M, D);
+        GemmEpi g;
+        g.bias = k.b1; g.act = ACT_GELU_TANH; g.out = f->ff; g.out_bf16 = 1; g.ldc = FF;
+        FY_TRY(gemm_bf16(f->xn, D, k.w1, M, FF, D, g, st));
+        GemmEpi r;
+        r.mode = EPI_GATE_RESID; r.bias = k.b2; r.resid = f->h; r.gate = m + 5 * D; r.ldc = D;
+        FY_TRY(gemm_bf16(f->ff, FF, k.w2, M, D, FF, r, st));
+    }
+    const float* fn = f->fin + (size_t)slot * 2 * D;            // (scale, shift), modules.py:261
+    hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, fn, fn + D, f->xn, M, D);
+    GemmEpi p;
+    p.bias = f->b_out; p.out = f->v; p.out_bf16 = 0; p.ldc = C;
+    FY_TRY(gemm_bf16(f->xn, D, f->w_out, M, C, D, p, st));
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, const int32_t* n_token, const int32_t* prompt_token,
+                             int32_t ptok_ld, const int32_t* n_prompt, const float* prompt_feat, int32_t pfeat_rows, const int32_t* n_pfeat,
+                             const float* embedding, const float* rand_noise, int32_t noise_ld, int32_t B, float* mel, int32_t mel_frames,
+                             uint32_t flags, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(f && token && n_token && n_prompt && n_pfeat && embedding && rand_noise && mel, FY_ERR_ARG, "fy_flow_infer: null argument");
+    FY_CHECK(B >= 1 && B <= f->max_batch, FY_ERR_ARG, "fy_flow_infer: batch %d outside [1, %d]", B, f->max_batch);
+    const fy_flow_config& c = f->cfg;
+    const int C = c.mel, mb = f->max_batch;
+    std::vector<int> lens(4 * mb, 0), sl(2 * mb, 0), npr(mb, 0);
+    int Tmax = 0, Nmax = 0;
+    for (int b = 0; b < B; ++b) {
+        int n_all = n_token[b] + n_prompt[b], T = 2 * n_all;
+        FY_CHECK(n_token[b] >= 1 && n_prompt[b] >= 0 && n_pfeat[b] >= 0 && n_pfeat[b] <= T && T <= f->Tmax && T <= noise_ld &&
+                     2 * n_token[b] <= mel_frames && n_token[b] <= tok_ld && n_prompt[b] <= ptok_ld && n_pfeat[b] <= pfeat_rows,
+                 FY_ERR_ARG, "fy_flow_infer: utterance %d has inconsistent lengths (tokens %d, prompt %d, prompt frames %d, max frames %d)",
+                 b, n_token[b], n_prompt[b], n_pfeat[b], f->Tmax);
+        lens[0 * mb + b] = n_all; lens[1 * mb + b] = T; lens[2 * mb + b] = n_pfeat[b]; lens[3 * mb + b] = n_prompt[b];
+        sl[2 * b] = sl[2 * b + 1] = T;
+        Tmax = std::max(Tmax, T); Nmax = std::max(Nmax, n_all);
+    }
+    HIP_TRY(hipMemcpyAsync(f->blen, lens.data(), lens.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(f->seq_len, sl.data(), sl.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int *d_nall = f->blen, *d_T = f->blen + mb, *d_pmel = f->blen + 2 * mb, *d_np = f->blen + 3 * mb;
+    // front: speaker projection, token embedding, PreLookahead (upsample_encoder.py:82-103)
+    hipLaunchKernelGGL(spk_k, dim3(B), dim3(256), 0, st, embedding, f->spk_w, f->spk_b, f->spks, c.spk_in, C);
+    hipLaunchKernelGGL(tok_embed_k, dim3(Nmax, B), dim3(128), 0, st, prompt_token, ptok_ld, token, tok_ld, d_np, d_nall, f->tok_all,
+                       f->emb_w, f->emb, Nmax, C, c.vocab);
+    {
+        ConvDesc d;
+        memset(&d, 0, sizeof(d));
+        d.B = B; d.dil = 1; d.stride = 1; d.up = 1; d.groups = 1; d.out_scale = 1.f;
+        d.x = f->emb; d.x_bs = (long)Nmax * C; d.x_ld = C; d.L_in = Nmax; d.in_len = d_nall;
+        d.y = f->pre_a; d.y_bs = (long)Nmax * c.pre_ch; d.y_ld = c.pre_ch; d.L_out = Nmax; d.out_len = d_nall;
+        d.Cin = C; d.Cout = c.pre_ch; d.KW = c.pre_lookahead + 1; d.pad_left = 0; d.bias = f->pre1.bias;
+        d.post_act = ACT_LEAKY; d.post_slope = 0.01f;
+        FY_TRY(conv1d_f32_direct(d, f->pre1, st));
+        ConvDesc e;
+        memset(&e, 0, sizeof(e));
+        e.B = B; e.dil = 1; e.stride = 1; e.up = 1; e.groups = 1; e.out_scale = 1.f;
+        e.x = f->pre_a; e.x_bs = (long)Nmax * c.pre_ch; e.x_ld = c.pre_ch; e.L_in = Nmax; e.in_len = d_nall;
+        e.y = f->mu_tok; e.y_bs = (long)Nmax * C; e.y_ld = C; e.L_out = Nmax; e.out_len = d_nall;
+        e.Cin = c.pre_ch; e.Cout = C; e.KW = 3; e.pad_left = 2; e.bias = f->pre2.bias;
+        e.add_resid = 1; e.resid = f->emb; e.r_bs = (long)Nmax * C; e.r_ld = C;
+        FY_TRY(conv1d_f32_direct(e, f->pre2, st));
+    }
+    hipLaunchKernelGGL(flow_setup_k, dim3(Tmax, B), dim3(128), 0, st, f->mu_tok, prompt_feat, (long)pfeat_rows * C, rand_noise, noise_ld, d_T,
+                       d_pmel, f->mu, f->cond, f->x, Tmax, Nmax, C);
+    for (int step = 0; step < c.n_timesteps; ++step) {
+        hipLaunchKernelGGL(dit_assemble_k, dim3(Tmax, 2 * B), dim3(4 * C), 0, st, f->x, f->cond, f->mu, f->spks, d_T, f->a_in, Tmax, C);
+        FY_TRY(dit_forward(f, 2 * B, Tmax, step, (flags & FY_STREAMING) != 0, flags, st));
+        hipLaunchKernelGGL(euler_k, dim3(Tmax, B), dim3(128), 0, st, f->x, f->v, d_T, Tmax, C, f->dt_of_step[step], c.cfg_rate);
+    }
+    // mel[b] = x[b][pmel:, :]^T in the reference's (B, 80, F) layout, flow.py:401
+    for (int b = 0; b < B; ++b) {
+        int F = 2 * n_token[b];
+        FY_TRY(transpose_blc_to_bcl(f->x + ((long)b * Tmax + n_pfeat[b]) * C, mel + (long)b * C * mel_frames, 1, C, F, 0, C, 0, st));
+    }
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+// The reference's estimator hand-off (flow_matching.py:126-153): raw device pointers of contiguous
+// x (B2,80,T), mask (B2,1,T), mu (B2,80,T), t (B2), spks (B2,80), cond (B2,80,T); result written into x.
+extern "C" int fy_dit_estimator(fy_flow* f, float* x, const float* mask, const float* mu, const float* t, const float* spks,
+                                const float* cond, int32_t T, int32_t B2, uint32_t flags, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(f && x && mu && t && spks && cond, FY_ERR_ARG, "fy_dit_estimator: null argument");
+    FY_CHECK(B2 >= 1 && B2 <= 2 * f->max_batch && T >= 1 && T <= f->Tmax, FY_ERR_ARG, "fy_dit_estimator: (B2 %d, T %d) outside the handle's limits", B2, T);
+    const fy_flow_config& c = f->cfg;
+    const int C = c.mel;
+    std::vector<float> th(B2), mh;
+    HIP_TRY(hipMemcpyAsync(th.data(), t, B2 * sizeof(float), hipMemcpyDeviceToHost, st));
+    std::vector<int> sl(2 * f->max_batch, 0);
+    if (mask) {
+        mh.resize((size_t)B2 * T);
+        HIP_TRY(hipMemcpyAsync(mh.data(), mask, mh.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int s = 0; s < B2; ++s) {
+        FY_CHECK(th[s] == th[0], FY_ERR_ARG, "fy_dit_estimator: all rows must share one timestep (as solve_euler passes it)");
+        int len = T;
+        if (mask) { len = 0; while (len < T && mh[(size_t)s * T + len] != 0.f) ++len; }
+        FY_CHECK(len >= 1, FY_ERR_ARG, "fy_dit_estimator: empty mask row %d", s);
+        sl[s] = len;
+    }
+    HIP_TRY(hipMemcpyAsync(f->seq_len, sl.data(), sl.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    FY_TRY(compute_mod(f, th.data(), 1, c.n_timesteps, st));
+    // stage the four inputs channels-last in h (fp32 scratch), then pack the bf16 operand rows
+    float* sx = f->h;
+    float* sc = sx + (size_t)B2 * T * C;
+    float* sm = sc + (size_t)B2 * T * C;
+    FY_TRY(transpose_bcl_to_blc(x, sx, B2, C, T, (long)C * T, (long)T * C, C, st));
+    FY_TRY(transpose_bcl_to_blc(cond, sc, B2, C, T, (long)C * T, (long)T * C, C, st));
+    FY_TRY(transpose_bcl_to_blc(mu, sm, B2, C, T, (long)C * T, (long)T * C, C, st));
+    // a_in rows: sequence s uses its own (x, cond, mu, spks): reuse dit_assemble_k per sequence with cfg = 0
+    // by viewing each sequence as "batch b = s" with a stride of 2 sequences
+    {
+        // pack directly: one launch per sequence keeps the kernel unchanged
+        for (int s = 0; s < B2; ++s) {
+            hipLaunchKernelGGL(dit_assemble_k, dim3(T, 1), dim3(4 * C), 0, st, sx + (size_t)s * T * C, sc + (size_t)s * T * C,
+                               sm + (size_t)s * T * C, spks + (size_t)s * C, f->seq_len + s, f->a_in + (size_t)s * T * 4 * C, T, C);
+        }
+    }
+    // a_in was written by rows of T (not f->Tmax): run the estimator with Tmax = T; h is overwritten only after a_in is complete
+    HIP_TRY(hipStreamSynchronize(st));
+    FY_TRY(dit_forward(f, B2, T, c.n_timesteps, (flags & FY_STREAMING) != 0, flags, st));
+    FY_TRY(transpose_blc_to_bcl(f->v, x, B2, C, T, (long)T * C, C, (long)C * T, st));
+    return FY_OK;
+}

@@ -1,0 +1,401 @@
+// Speech-token language model engine: CosyVoice3LM.inference -> Qwen2LM.inference_wrapper ->
+// Qwen2Encoder.forward_one_step, CosyVoice/cosyvoice/llm/llm.py:713-748, 511-525, 246-258, for a
+// batch of sequences, plus CosyVoiceModel.llm_job's silent-token filter (cli/model.py:101-129).
+//
+// The Qwen2 body (third-party `transformers`, pinned 4.51.3) is restated as kernels: RMSNorm,
+// q/k/v projections with bias, split-half RoPE (theta 1e6), grouped-query causal attention over an
+// fp32 KV cache, SwiGLU.  Weights are bf16 in HBM; activations, accumulation, the cache and the
+// softmaxes are fp32, so greedy token ids track an fp32 reference on the same (bf16-representable)
+// weights.  Prefill rows of all sequences are packed; decode runs one row per sequence with all
+// per-sequence state (positions, counts, stop flags) on the device, so a step needs no host sync.
+#include "attn.h"
+#include "gemm.h"
+#include "runtime.h"
+#include <algorithm>
+#include <math.h>
+
+struct LlmLayerW {
+    bf16_t *wqkv, *wo, *wgu, *wd;
+    float *bqkv, *ln1, *ln2;
+};
+
+struct fy_llm {
+    fy_llm_config cfg;
+    int max_batch = 0, max_ctx = 0, max_rows = 0;
+    DevPool pool;
+    std::vector<LlmLayerW> L;
+    float *norm_w = nullptr, *speech_emb = nullptr, *inv_freq = nullptr;
+    bf16_t *w_head = nullptr, *embed_tokens = nullptr;
+    float *Kc = nullptr, *Vc = nullptr;            // [layers][max_batch][kv_heads][max_ctx][64]
+    float *h, *xn, *qkv, *ao, *act, *hb, *logits, *partial, *logp_keep;
+    int *row_seq, *row_pos, *row_src, *last_row;
+    int *st;                                          // [8][max_batch]: pos, raw_n, n_out, done, run, min_len, max_len, (spare)
+    int *seq_ids;                                     // 0..max_batch-1
+    int B = 0;
+    int n_speech() const { return cfg.speech_tokens + 200; }
+    int qkv_dim() const { return (cfg.q_heads + 2 * cfg.kv_heads) * cfg.head_dim; }
+    size_t cache_layer() const { return (size_t)max_batch * cfg.kv_heads * max_ctx * cfg.head_dim; }
+};
+
+extern "C" void fy_llm_default_config(fy_llm_config* c) {
+    memset(c, 0, sizeof(*c));
+    c->hidden = 896; c->layers = 24; c->q_heads = 14; c->kv_heads = 2; c->head_dim = 64; c->inter = 4864;
+    c->vocab = 151936; c->speech_tokens = 6561; c->rms_eps = 1e-6f; c->rope_theta = 1e6f;
+}
+
+__constant__ int c_silent[11] = {1, 2, 28, 29, 55, 248, 494, 2241, 2242, 2322, 2323};   // cli/model.py:414
+
+// ---- kernels -------------------------------------------------------------------------------------------
+// lm_input rows (llm.py:728-740): src = id | kind<<30, kind 0 = embed_tokens (bf16), 1 = speech_embedding (fp32)
+__global__ void embed_rows_k(const int* __restrict__ src, const bf16_t* __restrict__ etok, const float* __restrict__ semb, float* __restrict__ h, int H) {
+    int r = blockIdx.x, s = src[r], id = s & 0x3FFFFFFF, kind = s >> 30;
+    for (int c = threadIdx.x; c < H; c += blockDim.x)
+        h[(long)r * H + c] = kind ? semb[(long)id * H + c] : bf16_to_f32(etok[(long)id * H + c]);
+}
+
+// Qwen2RMSNorm: w * (x * rsqrt(mean(x^2) + eps)).  One wave per row.
+__global__ __launch_bounds__(256) void rmsnorm_k(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int R, int H, float eps) {
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float* p = x + (long)row * H;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += p[c] * p[c];
+    float r = rsqrtf(wave_sum(s) / H + eps);
+    for (int c = lane; c < H; c += 64) y[(long)row * H + c] = w[c] * (p[c] * r);
+}
+
+// split-half RoPE on q (in place) and k (into the cache), v copied into the cache. One block per row.
+__global__ void rope_kv_k(float* __restrict__ qkv, float* __restrict__ Kc, float* __restrict__ Vc, const int* __restrict__ row_seq,
+                          const int* __restrict__ row_pos, const float* __restrict__ inv_freq, int Hq, int Hk, int max_ctx) {
+    const int r = blockIdx.x, seq = row_seq[r], pos = row_pos[r];
+    const int ld = (Hq + 2 * Hk) * 64;
+    float* row = qkv + (long)r * ld;
+    for (int i = threadIdx.x; i < (Hq + Hk) * 32; i += blockDim.x) {
+        int hd = i >> 5, d = i & 31;
+        float ang = (float)pos * inv_freq[d];
+        float cs = cosf(ang), sn = sinf(ang);
+        float a = row[hd * 64 + d], b = row[hd * 64 + d + 32];
+        float o0 = a * cs - b * sn, o1 = b * cs + a * sn;
+        if (hd < Hq) {
+            row[hd * 64 + d] = o0;
+            row[hd * 64 + d + 32] = o1;
+        } else {
+            float* kc = Kc + (((long)seq * Hk + (hd - Hq)) * max_ctx + pos) * 64;
+            kc[d] = o0;
+            kc[d + 32] = o1;
+        }
+    }
+    for (int i = threadIdx.x; i < Hk * 64; i += blockDim.x) {
+        int hk = i >> 6, d = i & 63;
+        Vc[(((long)seq * Hk + hk) * max_ctx + pos) * 64 + d] = row[(Hq + Hk) * 64 + i];
+    }
+}
+
+__global__ void gather_rows_k(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, int H) {
+    int b = blockIdx.x;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) dst[(long)b * H + c] = src[(long)idx[b] * H + c];
+}
+
+// log_softmax + greedy rule + stop / silent-token bookkeeping + next input embedding.
+// st rows: 0 pos, 1 raw_n, 2 n_out, 3 done, 4 silent run, 5 min_len, 6 max_len.
+__global__ __launch_bounds__(256) void sample_k(const float* __restrict__ logits, int n_all, int n_real, int* __restrict__ st, int mb,
+                                                int* __restrict__ out_ids, int out_ld, const float* __restrict__ semb,
+                                                float* __restrict__ h, int H, float* __restrict__ logp_keep, int keep_step) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (st[3 * mb + b]) return;
+    const float* x = logits + (long)b * n_all;
+    float mx = -3.0e38f;
+    for (int i = tid; i < n_all; i += 256) mx = fmaxf(mx, x[i]);
+    sv[tid] = mx;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) sv[tid] = fmaxf(sv[tid], sv[tid + o]); __syncthreads(); }
+    mx = sv[0];
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < n_all; i += 256) s += expf(x[i] - mx);
+    sv[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) sv[tid] += sv[tid + o]; __syncthreads(); }
+    const float lse = logf(sv[0]);
+    __syncthreads();
+    const int raw_n = st[1 * mb + b];
+    const int lim = raw_n < st[5 * mb + b] ? n_real : n_all;       // eos forbidden below min_len
+    float best = -3.0e38f;
+    int bi = 0x7FFFFFFF;
+    for (int i = tid; i < n_all; i += 256) {
+        float lp = (x[i] - mx) - lse;
+        if (logp_keep && keep_step >= 0) logp_keep[((long)keep_step * mb + b) * n_all + i] = lp;
+        if (i < lim && (lp > best || (lp == best && i < bi))) { best = lp; bi = i; }
+    }
+    sv[tid] = best; si[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            float ov = sv[tid + o]; int oi = si[tid + o];
+            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) { sv[tid] = ov; si[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    const int id = si[0];
+    if (id >= n_real) {                      // stop_token_ids, llm.py:520
+        if (tid == 0) st[3 * mb + b] = 1;
+        return;
+    }
+    for (int c = tid; c < H; c += 256) h[(long)b * H + c] = semb[(long)id * H + c];      // llm.py:525
+    if (tid == 0) {
+        int run = st[4 * mb + b];
+        bool silent = false;
+        for (int k = 0; k < 11; ++k) silent |= (c_silent[k] == id);
+        bool keep = true;
+        if (silent) { run += 1; if (run > 5) keep = false; } else run = 0;      // cli/model.py:121-127
+        st[4 * mb + b] = run;
+        if (keep) { int n = st[2 * mb + b]; if (n < out_ld) out_ids[(long)b * out_ld + n] = id; st[2 * mb + b] = n + 1; }
+        st[1 * mb + b] = raw_n + 1;
+        st[0 * mb + b] += 1;                                                   // the new token's position
+        if (raw_n + 1 >= st[6 * mb + b]) st[3 * mb + b] = 1;                   // for i in range(max_len), llm.py:514
+    }
+}
+
+// ---- create -------------------------------------------------------------------------------------------------
+static int to_bf16(fy_llm* l, const float* src, size_t n, bf16_t** dst, hipStream_t st) {
+    FY_TRY(l->pool.alloc(dst, n));
+    return cast_f32_bf16(src, *dst, n, st);
+}
+static int copy_f32(fy_llm* l, const float* src, size_t n, float** dst, hipStream_t st) {
+    FY_TRY(l->pool.alloc(dst, n));
+    HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return FY_OK;
+}
+
+// rows (gate_i, up_i) interleaved so one wave owns both halves of a SwiGLU pair
+__global__ void interleave_gu_k(const float* __restrict__ g, const float* __restrict__ u, bf16_t* __restrict__ out, int inter, int H) {
+    long n = (long)2 * inter * H;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        long row = i / H;
+        int c = (int)(i % H);
+        const float* src = (row & 1) ? u : g;
+        out[i] = f32_to_bf16(src[(row >> 1) * H + c]);
+    }
+}
+
+extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_tensor* weights, int32_t n_weights,
+                             int32_t max_batch, int32_t max_ctx, void* stream) {
+    FY_CHECK(out && max_batch >= 1 && max_ctx >= 8, FY_ERR_ARG, "fy_llm_create: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    fy_llm* l = new fy_llm();
+    if (cfg) l->cfg = *cfg; else fy_llm_default_config(&l->cfg);
+    const fy_llm_config& c = l->cfg;
+    auto fail = [&](int code) { delete l; return code; };
+    if (c.head_dim != 64 || c.q_heads % c.kv_heads != 0 || c.hidden % 8 != 0 || c.inter % 8 != 0 || c.q_heads * c.head_dim != c.hidden) {
+        fy_set_error("fy_llm_create: unsupported architecture (hidden %d, heads %d/%d x %d)", c.hidden, c.q_heads, c.kv_heads, c.head_dim);
+        return fail(FY_ERR_ARG);
+    }
+    l->max_batch = max_batch; l->max_ctx = max_ctx; l->max_rows = max_batch * max_ctx;
+    Weights W;
+    int rc = W.init(weights, n_weights);
+    if (rc) return fail(rc);
+#define TRYC(e) do { int _r = (e); if (_r) return fail(_r); } while (0)
+#define GETW(var, name, ...) const float* var = W.get(name, {__VA_ARGS__}); if (!var) return fail(FY_ERR_WEIGHT)
+    const int H = c.hidden, Q = c.q_heads * 64, KV = c.kv_heads * 64, I = c.inter, NS = l->n_speech();
+    const std::string P = "llm.model.model.";
+    l->L.resize(c.layers);
+    for (int i = 0; i < c.layers; ++i) {
+        const std::string p = P + "layers." + std::to_string(i) + ".";
+        LlmLayerW& k = l->L[i];
+        GETW(qw, p + "self_attn.q_proj.weight", Q, H); GETW(qb, p + "self_attn.q_proj.bias", Q);
+        GETW(kw, p + "self_attn.k_proj.weight", KV, H); GETW(kb, p + "self_attn.k_proj.bias", KV);
+        GETW(vw, p + "self_attn.v_proj.weight", KV, H); GETW(vb, p + "self_attn.v_proj.bias", KV);
+        GETW(ow, p + "self_attn.o_proj.weight", H, Q);
+        GETW(gw, p + "mlp.gate_proj.weight", I, H); GETW(uw, p + "mlp.up_proj.weight", I, H);
+        GETW(dw, p + "mlp.down_proj.weight", H, I);
+        GETW(n1, p + "input_layernorm.weight", H); GETW(n2, p + "post_attention_layernorm.weight", H);
+        TRYC(l->pool.alloc(&k.wqkv, (size_t)(Q + 2 * KV) * H));
+        TRYC(l->pool.alloc(&k.bqkv, (size_t)(Q + 2 * KV)));
+        TRYC(cast_f32_bf16(qw, k.wqkv, (size_t)Q * H, st));
+        TRYC(cast_f32_bf16(kw, k.wqkv + (size_t)Q * H, (size_t)KV * H, st));
+        TRYC(cast_f32_bf16(vw, k.wqkv + (size_t)(Q + KV) * H, (size_t)KV * H, st));
+        if (hipMemcpyAsync(k.bqkv, qb, Q * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(k.bqkv + Q, kb, KV * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(k.bqkv + Q + KV, vb, KV * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            fy_set_error("fy_llm_create: bias copy failed");
+            return fail(FY_ERR_HIP);
+        }
+        TRYC(to_bf16(l, ow, (size_t)H * Q, &k.wo, st));
+        TRYC(l->pool.alloc(&k.wgu, (size_t)2 * I * H));
+        hipLaunchKernelGGL(interleave_gu_k, dim3(4096), dim3(256), 0, st, gw, uw, k.wgu, I, H);
+        TRYC(to_bf16(l, dw, (size_t)H * I, &k.wd, st));
+        TRYC(copy_f32(l, n1, H, &k.ln1, st)); TRYC(copy_f32(l, n2, H, &k.ln2, st));
+    }
+    {
+        GETW(nw, P + "norm.weight", H);
+        GETW(hw, "llm_decoder.weight", NS, H);
+        GETW(sw, "speech_embedding.weight", NS, H);
+        GETW(ew, P + "embed_tokens.weight", c.vocab, H);
+        TRYC(copy_f32(l, nw, H, &l->norm_w, st));
+        TRYC(to_bf16(l, hw, (size_t)NS * H, &l->w_head, st));
+        TRYC(copy_f32(l, sw, (size_t)NS * H, &l->speech_emb, st));
+        TRYC(to_bf16(l, ew, (size_t)c.vocab * H, &l->embed_tokens, st));
+    }
+    {
+        std::vector<float> inv(32);
+        for (int i = 0; i < 32; ++i) inv[i] = 1.0f / powf(c.rope_theta, (float)(2 * i) / 64.0f);
+        TRYC(l->pool.alloc(&l->inv_freq, 32));
+        if (hipMemcpyAsync(l->inv_freq, inv.data(), 32 * sizeof(float), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            fy_set_error("fy_llm_create: upload failed");
+            return fail(FY_ERR_HIP);
+        }
+    }
+    const size_t R = l->max_rows, B = max_batch;
+    TRYC(l->pool.alloc(&l->Kc, (size_t)c.layers * l->cache_layer()));
+    TRYC(l->pool.alloc(&l->Vc, (size_t)c.layers * l->cache_layer()));
+    TRYC(l->pool.alloc(&l->h, R * H)); TRYC(l->pool.alloc(&l->xn, R * H)); TRYC(l->pool.alloc(&l->qkv, R * l->qkv_dim()));
+    TRYC(l->pool.alloc(&l->ao, R * H)); TRYC(l->pool.alloc(&l->act, R * I)); TRYC(l->pool.alloc(&l->hb, B * H));
+    TRYC(l->pool.alloc(&l->logits, B * NS)); TRYC(l->pool.alloc(&l->partial, gemv_partial_floats((int)R, H, I) + 16));
+    TRYC(l->pool.alloc(&l->logp_keep, (size_t)FY_LLM_KEEP_LOGP * B * NS));
+    TRYC(l->pool.alloc(&l->row_seq, R)); TRYC(l->pool.alloc(&l->row_pos, R)); TRYC(l->pool.alloc(&l->row_src, R));
+    TRYC(l->pool.alloc(&l->last_row, B)); TRYC(l->pool.alloc(&l->st, 8 * B)); TRYC(l->pool.alloc(&l->seq_ids, B));
+    {
+        std::vector<int> ids(B);
+        for (size_t i = 0; i < B; ++i) ids[i] = (int)i;
+        if (hipMemcpyAsync(l->seq_ids, ids.data(), B * sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess) {
+            fy_set_error("fy_llm_create: upload failed");
+            return fail(FY_ERR_HIP);
+        }
+    }
+#undef GETW
+#undef TRYC
+    if (hipStreamSynchronize(st) != hipSuccess) { fy_set_error("fy_llm_create: stream sync failed"); return fail(FY_ERR_HIP); }
+    *out = l;
+    return FY_OK;
+}
+
+extern "C" void fy_llm_destroy(fy_llm* l) { delete l; }
+
+// ---- forward over R rows (prefill rows or one decode row per sequence) ---------------------------------------------
+static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, hipStream_t st) {
+    const fy_llm_config& c = l->cfg;
+    const int H = c.hidden, I = c.inter, QKV = l->qkv_dim();
+    for (int i = 0; i < c.layers; ++i) {
+        const LlmLayerW& k = l->L[i];
+        float* Kc = l->Kc + (size_t)i * l->cache_layer();
+        float* Vc = l->Vc + (size_t)i * l->cache_layer();
+        hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln1, l->xn, R, H, c.rms_eps);
+        GemvArgs a;
+        a.W = k.wqkv; a.x = l->xn; a.ldx = H; a.R = R; a.N = QKV; a.K = H; a.bias = k.bqkv; a.y = l->qkv; a.ldy = QKV;
+        FY_TRY(gemv_bf16w(a, st));
+        hipLaunchKernelGGL(rope_kv_k, dim3(R), dim3(256), 0, st, l->qkv, Kc, Vc, row_seq, row_pos, l->inv_freq, c.q_heads, c.kv_heads, l->max_ctx);
+        FY_TRY(llm_attention(l->qkv, QKV, Kc, Vc, row_seq, row_pos, l->ao, H, R, c.q_heads, c.kv_heads, l->max_ctx, st));
+        GemvArgs o;
+        o.W = k.wo; o.x = l->ao; o.ldx = H; o.R = R; o.N = H; o.K = H; o.y = l->h; o.ldy = H; o.mode = GV_ADD;
+        FY_TRY(gemv_bf16w(o, st));
+        hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln2, l->xn, R, H, c.rms_eps);
+        GemvArgs g;
+        g.W = k.wgu; g.x = l->xn; g.ldx = H; g.R = R; g.N = 2 * I; g.K = H; g.y = l->act; g.ldy = I; g.mode = GV_SWIGLU;
+        FY_TRY(gemv_bf16w(g, st));
+        GemvArgs d;
+        d.W = k.wd; d.x = l->act; d.ldx = I; d.R = R; d.N = H; d.K = I; d.y = l->h; d.ldy = H; d.mode = GV_ADD; d.partial = l->partial;
+        FY_TRY(gemv_bf16w(d, st));
+    }
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+static int llm_head_and_sample(fy_llm* l, int B, const float* rows, int32_t* out_ids, int out_ld, int keep_step, hipStream_t st) {
+    const fy_llm_config& c = l->cfg;
+    const int H = c.hidden, NS = l->n_speech();
+    hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(B, 4)), dim3(256), 0, st, rows, l->norm_w, l->xn, B, H, c.rms_eps);
+    GemvArgs a;
+    a.W = l->w_head; a.x = l->xn; a.ldx = H; a.R = B; a.N = NS; a.K = H; a.y = l->logits; a.ldy = NS;
+    FY_TRY(gemv_bf16w(a, st));
+    hipLaunchKernelGGL(sample_k, dim3(B), dim3(256), 0, st, l->logits, NS, c.speech_tokens, l->st, l->max_batch, out_ids, out_ld,
+                       l->speech_emb, l->h, H, l->logp_keep, keep_step < FY_LLM_KEEP_LOGP ? keep_step : -1);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+extern "C" int fy_llm_generate(fy_llm* l, const int32_t* text_ids, const int32_t* n_text_all, const int32_t* prompt_speech,
+                               const int32_t* n_prompt_speech, const int32_t* min_len, const int32_t* max_len, int32_t B,
+                               int32_t* out_ids, int32_t out_ld, int32_t* out_n, int32_t* raw_n, uint32_t flags, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(l && text_ids && n_text_all && n_prompt_speech && min_len && max_len && out_ids && out_n, FY_ERR_ARG, "fy_llm_generate: null argument");
+    FY_CHECK(B >= 1 && B <= l->max_batch && out_ld >= 1, FY_ERR_ARG, "fy_llm_generate: batch %d outside [1, %d]", B, l->max_batch);
+    const fy_llm_config& c = l->cfg;
+    const int mb = l->max_batch, H = c.hidden;
+    // lm_input = [sos, embed(prompt_text + text), task_id, speech_embedding(prompt_speech)], llm.py:732-740
+    std::vector<int> src, rseq, rpos, last(mb, 0), stv(8 * mb, 0);
+    int to = 0, po = 0, steps = 0;
+    for (int b = 0; b < B; ++b) {
+        const int nt = n_text_all[b], np = n_prompt_speech[b], Lb = 2 + nt + np;
+        FY_CHECK(nt >= 1 && np >= 0 && min_len[b] >= 0 && max_len[b] >= 1, FY_ERR_ARG, "fy_llm_generate: sequence %d has bad lengths", b);
+        FY_CHECK(Lb + max_len[b] <= l->max_ctx, FY_ERR_ARG, "fy_llm_generate: sequence %d needs %d positions, the handle has %d", b,
+                 Lb + max_len[b], l->max_ctx);
+        FY_CHECK(np == 0 || prompt_speech, FY_ERR_ARG, "fy_llm_generate: prompt_speech is null");
+        for (int p = 0; p < Lb; ++p) {
+            int s;
+            if (p == 0) s = c.speech_tokens | (1 << 30);
+            else if (p <= nt) {
+                int id = text_ids[to + p - 1];
+                FY_CHECK(id >= 0 && id < c.vocab, FY_ERR_ARG, "fy_llm_generate: text id %d outside the vocabulary", id);
+                s = id;
+            } else if (p == nt + 1) s = (c.speech_tokens + 2) | (1 << 30);
+            else {
+                int id = prompt_speech[po + p - nt - 2];
+                FY_CHECK(id >= 0 && id < l->n_speech(), FY_ERR_ARG, "fy_llm_generate: prompt speech id %d out of range", id);
+                s = id | (1 << 30);
+            }
+            src.push_back(s); rseq.push_back(b); rpos.push_back(p);
+        }
+        last[b] = (int)src.size() - 1;
+        stv[0 * mb + b] = Lb - 1;          // position of the last prefill token; sample_k advances it
+        stv[5 * mb + b] = min_len[b];
+        stv[6 * mb + b] = max_len[b];
+        to += nt; po += np;
+        steps = std::max(steps, (int)max_len[b]);
+    }
+    for (int b = B; b < mb; ++b) stv[3 * mb + b] = 1;
+    const int R = (int)src.size();
+    FY_CHECK(R <= l->max_rows, FY_ERR_ARG, "fy_llm_generate: %d prefill rows exceed the workspace (%d)", R, l->max_rows);
+    HIP_TRY(hipMemcpyAsync(l->row_src, src.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(l->row_seq, rseq.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(l->row_pos, rpos.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(l->last_row, last.data(), mb * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(l->st, stv.data(), stv.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    l->B = B;
+    // prefill
+    hipLaunchKernelGGL(embed_rows_k, dim3(R), dim3(256), 0, st, l->row_src, l->embed_tokens, l->speech_emb, l->h, H);
+    FY_TRY(llm_layers(l, R, l->row_seq, l->row_pos, st));
+    hipLaunchKernelGGL(gather_rows_k, dim3(B), dim3(256), 0, st, l->h, l->last_row, l->hb, H);
+    FY_TRY(llm_head_and_sample(l, B, l->hb, out_ids, out_ld, 0, st));
+    // decode: row b = sequence b at position st[pos][b]; everything a step needs is on the device
+    std::vector<int> done(mb);
+    for (int step = 1; step < steps; ++step) {
+        FY_TRY(llm_layers(l, B, l->seq_ids, l->st, st));
+        FY_TRY(llm_head_and_sample(l, B, l->h, out_ids, out_ld, step, st));
+        if ((step & 7) == 7) {
+            HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            bool all = true;
+            for (int b = 0; b < B; ++b) all = all && done[b];
+            if (all) break;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(out_n, l->st + 2 * mb, B * sizeof(int), hipMemcpyDeviceToDevice, st));
+    if (raw_n) HIP_TRY(hipMemcpyAsync(raw_n, l->st + 1 * mb, B * sizeof(int), hipMemcpyDeviceToDevice, st));
+    (void)flags;
+    return FY_OK;
+}
+
+extern "C" int fy_llm_logp(fy_llm* l, int32_t step, float* dst, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(l && dst && step >= 0 && step < FY_LLM_KEEP_LOGP && l->B > 0, FY_ERR_ARG, "fy_llm_logp: bad argument or no call made yet");
+    const int NS = l->n_speech();
+    for (int b = 0; b < l->B; ++b)
+        HIP_TRY(hipMemcpyAsync(dst + (size_t)b * NS, l->logp_keep + ((size_t)step * l->max_batch + b) * NS, NS * sizeof(float),
+                               hipMemcpyDeviceToDevice, st));
+    return FY_OK;
+}

@@ -1,0 +1,80 @@
+"""Host side of the speech-token LM: mirrors `CosyVoice3LM.inference`
+(CosyVoice/cosyvoice/llm/llm.py:713-748) plus the token filter of
+`CosyVoiceModel.llm_job` (cli/model.py:101-129) over the C ABI, for a batch."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .spec import LlmCfg
+
+
+def _cfg_struct(cfg: LlmCfg) -> _lib.LlmConfig:
+    c = _lib.LlmConfig()
+    _lib.lib().fy_llm_default_config(C.byref(c))
+    c.hidden, c.layers, c.q_heads, c.kv_heads, c.head_dim = cfg.hidden, cfg.layers, cfg.q_heads, cfg.kv_heads, cfg.head_dim
+    c.inter, c.vocab, c.speech_tokens, c.rms_eps, c.rope_theta = cfg.inter, cfg.vocab, cfg.speech_tokens, cfg.rms_eps, cfg.rope_theta
+    return c
+
+
+class LlmEngine:
+    """weights: the llm.pt state_dict (reference key names, fp32 CUDA tensors; lm_head not needed)."""
+
+    def __init__(self, weights: Dict[str, torch.Tensor], cfg: LlmCfg = LlmCfg(), max_batch: int = 8, max_ctx: int = 1024,
+                 device: Optional[torch.device] = None):
+        self.cfg = cfg
+        self.device = device or next(iter(weights.values())).device
+        self.max_batch, self.max_ctx = max_batch, max_ctx
+        self._h = C.c_void_p()
+        weights = {k: v for k, v in weights.items() if "lm_head" not in k}
+        arr, keep = _lib.tensor_table(weights)
+        cs = _cfg_struct(cfg)
+        with torch.cuda.device(self.device):
+            check(_lib.lib().fy_llm_create(C.byref(self._h), C.byref(cs), arr, len(weights), max_batch, max_ctx, self._stream()))
+        del keep
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if self._h:
+            _lib.lib().fy_llm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def generate(self, text: Sequence[Sequence[int]], prompt_text: Sequence[Sequence[int]],
+                 prompt_speech: Sequence[Sequence[int]], min_len: Optional[Sequence[int]] = None,
+                 max_len: Optional[Sequence[int]] = None, min_ratio: float = 2, max_ratio: float = 20):
+        """Per-sequence python lists of ids -> (out_ids (B, max(max_len)) int32 CUDA, out_n (B) CUDA, raw_n (B) CUDA).
+        min/max default to llm.py:743-744 (2x / 20x the text-only length)."""
+        B = len(text)
+        ids, n_all, ps, n_ps = [], [], [], []
+        for b in range(B):
+            ids += list(prompt_text[b]) + list(text[b])
+            n_all.append(len(prompt_text[b]) + len(text[b]))
+            ps += list(prompt_speech[b])
+            n_ps.append(len(prompt_speech[b]))
+        mn = [int(len(text[b]) * min_ratio) for b in range(B)] if min_len is None else list(min_len)
+        mx = [int(len(text[b]) * max_ratio) for b in range(B)] if max_len is None else list(max_len)
+        out_ld = max(mx)
+        out = torch.zeros(B, out_ld, dtype=torch.int32, device=self.device)
+        out_n = torch.zeros(B, dtype=torch.int32, device=self.device)
+        raw_n = torch.zeros(B, dtype=torch.int32, device=self.device)
+        check(_lib.lib().fy_llm_generate(self._h, _lib.int_array(ids), _lib.int_array(n_all), _lib.int_array(ps or [0]),
+                                         _lib.int_array(n_ps), _lib.int_array(mn), _lib.int_array(mx), B, out.data_ptr(), out_ld,
+                                         out_n.data_ptr(), raw_n.data_ptr(), 0, self._stream()))
+        return out, out_n, raw_n
+
+    def logp(self, step: int, B: int) -> torch.Tensor:
+        buf = torch.empty(B, self.cfg.n_speech, device=self.device)
+        check(_lib.lib().fy_llm_logp(self._h, step, buf.data_ptr(), self._stream()))
+        return buf

@@ -34,7 +34,8 @@ int fy_version(void);
 
 /* ---- flags ------------------------------------------------------------------ */
 #define FY_PRECISE 1u /* split-bf16 (hi+lo) activations on the MFMA paths: fp32-class accuracy, 2x MFMA work */
-#define FY_DIRECT 2u  /* HiFT: run every convolution on the exact fp32 VALU kernel */
+#define FY_DIRECT 2u  /* HiFT / DiT position conv: run convolutions on the exact fp32 VALU kernel */
+#define FY_STREAMING 4u /* flow: block-causal chunk attention mask (streaming=True in the reference) */
 
 /* ================================ HiFT vocoder ================================
  * replaces CausalHiFTGenerator.inference(speech_feat, finalize=True)
@@ -79,6 +80,75 @@ int fy_hift_tap(fy_hift* h, const char* name, float* dst, int64_t* rows, int64_t
 /* one ResBlock (generator.py:110-117) of the main stack, index 0..8, on x (B, L, C) channels-last, in -> out.
  * The microbenchmark entry for BASELINE config 5.                                                           */
 int fy_hift_resblock(fy_hift* h, int32_t index, const float* x, float* y, int32_t B, int32_t L, uint32_t flags, void* stream);
+
+/* ============================ flow-matching decoder ============================
+ * replaces CausalMaskedDiffWithDiT.inference(token, ..., prompt_feat, embedding, streaming, finalize=True)
+ *   cosyvoice/flow/flow.py:358-403 (called from cli/model.py:418-427)                                   */
+typedef struct fy_flow fy_flow;
+
+typedef struct fy_flow_config {          /* cosyvoice3.yaml:38-75 */
+    int32_t mel, spk_in, vocab, pre_ch, pre_lookahead;
+    int32_t dim, depth, heads, head_dim, ff_mult, conv_pos_k, conv_pos_groups;
+    int32_t n_timesteps;                 /* 10, flow.py:398 */
+    float cfg_rate;                      /* inference_cfg_rate 0.7 */
+    int32_t static_chunk;                /* chunk_size * token_mel_ratio = 50 */
+    float t_span[33];                    /* 1 - cos(linspace(0,1,n+1)*pi/2), flow_matching.py:223-225 */
+} fy_flow_config;
+
+void fy_flow_default_config(fy_flow_config* cfg);
+
+/* weights: the tensors of flow.pt under their state_dict names. max_frames bounds prompt + generated mel frames. */
+int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy_tensor* weights, int32_t n_weights,
+                   int32_t max_batch, int32_t max_frames, void* stream);
+void fy_flow_destroy(fy_flow* f);
+
+/* token (B, tok_ld) int32, prompt_token (B, ptok_ld) int32, prompt_feat (B, pfeat_rows, 80) fp32,
+ * embedding (B, 192) fp32 - device; n_token / n_prompt / n_pfeat - host int32[B];
+ * rand_noise (80, noise_ld): the reference's fixed CausalConditionalCFM.rand_noise (flow_matching.py:199-200);
+ * mel out (B, 80, mel_frames), utterance b fills frames [0, 2*n_token[b]).                                     */
+int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, const int32_t* n_token, const int32_t* prompt_token,
+                  int32_t ptok_ld, const int32_t* n_prompt, const float* prompt_feat, int32_t pfeat_rows, const int32_t* n_pfeat,
+                  const float* embedding, const float* rand_noise, int32_t noise_ld, int32_t B, float* mel, int32_t mel_frames,
+                  uint32_t flags, void* stream);
+
+/* replaces the estimator hand-off ConditionalCFM.forward_estimator uses for a non-nn.Module estimator
+ *   cosyvoice/flow/flow_matching.py:126-153: contiguous x (B2,80,T), mask (B2,1,T), mu (B2,80,T), t (B2),
+ *   spks (B2,80), cond (B2,80,T); the result overwrites x.                                                   */
+int fy_dit_estimator(fy_flow* f, float* x, const float* mask, const float* mu, const float* t, const float* spks,
+                     const float* cond, int32_t T, int32_t B2, uint32_t flags, void* stream);
+
+/* ============================ speech-token language model ============================
+ * replaces CosyVoice3LM.inference(...) + CosyVoiceModel.llm_job's token filter
+ *   cosyvoice/llm/llm.py:713-748, 511-525; cosyvoice/cli/model.py:101-129                   */
+typedef struct fy_llm fy_llm;
+
+typedef struct fy_llm_config {           /* Qwen2-0.5B body + CosyVoice3LM heads, llm/llm.py:641-668 */
+    int32_t hidden, layers, q_heads, kv_heads, head_dim, inter, vocab, speech_tokens;
+    float rms_eps, rope_theta;
+} fy_llm_config;
+
+void fy_llm_default_config(fy_llm_config* cfg);
+
+/* weights: the tensors of llm.pt under their state_dict names (lm_head is not needed). max_ctx bounds
+ * prefill + generated positions per sequence.                                                           */
+int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_tensor* weights, int32_t n_weights,
+                  int32_t max_batch, int32_t max_ctx, void* stream);
+void fy_llm_destroy(fy_llm* l);
+
+/* Greedy generation for B sequences.  text ids = concat[prompt_text, text] per sequence (host int32,
+ * packed back to back, n_text_all[b] each); prompt_speech (host int32, packed, n_prompt_speech[b] each);
+ * min_len / max_len host int32[B] (llm.py:743-744: 2x / 20x the text-only length).
+ * out_ids (B, out_ld) device int32 receives the emitted speech tokens after the silent-token filter
+ * (cli/model.py:121-128); out_n (B) device int32 their count; raw_n (nullable, B) the count before the filter.
+ * Greedy rule: argmax of log_softmax; while fewer than min_len tokens were emitted the
+ * argmax runs over the real speech tokens only; an id >= speech_tokens ends the sequence.                   */
+int fy_llm_generate(fy_llm* l, const int32_t* text_ids, const int32_t* n_text_all, const int32_t* prompt_speech,
+                    const int32_t* n_prompt_speech, const int32_t* min_len, const int32_t* max_len, int32_t B,
+                    int32_t* out_ids, int32_t out_ld, int32_t* out_n, int32_t* raw_n, uint32_t flags, void* stream);
+/* log_softmax of step `step` (0 = first generated token) of the last fy_llm_generate call, (B, speech_tokens+200).
+ * Only the first FY_LLM_KEEP_LOGP steps are kept.                                                            */
+#define FY_LLM_KEEP_LOGP 4
+int fy_llm_logp(fy_llm* l, int32_t step, float* dst, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,84 @@
+"""GPU parity: the HIP speech-token LM through the C ABI against the fixtures minted from the
+reference (real Qwen2ForCausalLM + CosyVoice3LM.inference) and the CPU oracle.
+
+Token ids: bit-exact under greedy decode (weights bf16-representable, activations fp32).
+log-probabilities of the first steps: |diff| <= 2e-3 (fp32 accumulation order).
+"""
+import numpy as np
+import pytest
+import torch
+
+from _digest import check
+from fangyan_tts_amd import synth
+from fangyan_tts_amd.spec import LlmCfg
+from gpu_util import golden, llm_case, note, to_dev
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def make(cfg, max_batch=4, max_ctx=512):
+    from fangyan_tts_amd.llm import LlmEngine
+    sd = synth.state_dict(cfg.manifest(), skip=("lm_head",))
+    return LlmEngine(to_dev(sd, DEV), cfg, max_batch=max_batch, max_ctx=max_ctx)
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return make(LlmCfg.tiny())
+
+
+@pytest.fixture(scope="module")
+def full():
+    return make(LlmCfg(), max_batch=2, max_ctx=256)
+
+
+def run_cases(eng, f, cases, cap, tagname):
+    cfg = eng.cfg
+    texts, ptexts, ptoks, refs = [], [], [], []
+    for c in cases:
+        ctag = "%d_%d_%d" % c
+        t, pt, pk = llm_case(cfg, *c, ctag)
+        texts.append(t); ptexts.append(pt); ptoks.append(pk)
+        refs.append(f[f"c{ctag}.tokens"].tolist())
+    max_len = [cap if cap else int(len(t) * 20) for t in texts]
+    out, out_n, raw_n = eng.generate(texts, ptexts, ptoks, max_len=max_len)
+    out, out_n = out.cpu(), out_n.cpu().tolist()
+    for b, c in enumerate(cases):
+        got = out[b, : out_n[b]].tolist()
+        ref = refs[b][: cap] if cap else refs[b]
+        first_bad = next((i for i, (g, r) in enumerate(zip(got, ref)) if g != r), None)
+        note("parity_llm.json", f"{tagname}.{c}.n", [len(got), len(ref), first_bad])
+        assert got == ref, (c, first_bad, got[:10], ref[:10])
+        ctag = "%d_%d_%d" % c
+        for s in range(3):
+            lp = eng.logp(s, len(cases))[b].cpu()
+            check(lp, f, f"c{ctag}.logp{s}", 1e-3, 2e-3)
+
+
+def test_tiny_tokens_bit_exact_batched(tiny):
+    f = golden("llm_tiny.npz")
+    assert f is not None
+    run_cases(tiny, f, [(12, 8, 0), (10, 6, 30)], None, "tiny")
+
+
+def test_tiny_solo_equals_batched(tiny):
+    f = golden("llm_tiny.npz")
+    run_cases(tiny, f, [(10, 6, 30)], None, "tiny_solo")
+
+
+def test_full_tokens_bit_exact(full):
+    f = golden("llm_full.npz")
+    if f is None:
+        pytest.skip("llm_full.npz not minted")
+    run_cases(full, f, [(12, 8, 0), (14, 10, 40)], 60, "full")
+
+
+def test_forced_length_and_min_len(tiny):
+    """min_len = max_len = n (the benchmark's forced length) emits exactly n real speech tokens."""
+    cfg = tiny.cfg
+    t, pt, pk = llm_case(cfg, 10, 6, 30, "10_6_30")
+    out, out_n, raw_n = tiny.generate([t, t], [pt, pt], [pk, []], min_len=[40, 33], max_len=[40, 33])
+    assert raw_n.cpu().tolist() == [40, 33]
+    o = out.cpu()
+    assert int(o[0, :40].max()) < cfg.speech_tokens and int(o[1, :33].max()) < cfg.speech_tokens
