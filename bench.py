@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Benchmark of the north-star path: CosyVoice3-0.5B instruct inference, batch 8 per GPU.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the hot path (speech-token LM greedy decode -> 10-step CFG flow matching over
+the DiT -> HiFT vocoder) over one batch of 8 synthetic instruct utterances per GPU, inputs resident
+in HBM, outputs (wavs) resident in HBM; with N > 1 every rank runs its own 8 utterances
+(data-parallel, no data-path collective) and one RCCL all-gather collects the finished audio.
+
+Workload (cfg 2 = BASELINE.json configs[1]): instruct text 8 ids + tts text U{10..20} ids,
+5 s prompt (125 speech tokens / 250 mel frames, x-vector 192), forced length n = 75 tokens per
+utterance (3 s of audio each), random-init weights of the CosyVoice3-0.5B architecture
+(fangyan_tts_amd.synth), bf16 MFMA arithmetic for DiT / HiFT, fp32 activations in the LM.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_TOK = 75            # forced speech tokens per utterance (3 s)
+P_TOK = 125           # prompt speech tokens (5 s)
+BATCH = 8
+PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def make_inputs(cfg, rank):
+    import numpy as np
+    from fangyan_tts_amd import synth
+    inputs = []
+    for b in range(BATCH):
+        tag = f"bench.r{rank}.u{b}"
+        n_text = 10 + int(synth.randint(tag + ".len", (1,), 0, 11)[0])
+        hi = min(cfg.llm.vocab, 151643)
+        mel = np.clip(synth.normal(tag + ".pfeat", (1, 2 * P_TOK, 80), -5.0, 2.0), -11.5, 2.0)
+        inputs.append({
+            "text": torch.from_numpy(synth.randint(tag + ".text", (1, n_text), 0, hi)),
+            "prompt_text": torch.from_numpy(synth.randint(tag + ".instruct", (1, 8), 0, hi)),
+            "llm_prompt_speech_token": torch.zeros(1, 0, dtype=torch.int32),        # instruct2 drops it, frontend.py:209-213
+            "flow_prompt_speech_token": torch.from_numpy(synth.randint(tag + ".ptok", (1, P_TOK), 0, cfg.flow.vocab)),
+            "prompt_speech_feat": torch.from_numpy(mel),
+            "flow_embedding": torch.from_numpy(synth.normal(tag + ".spk", (1, 192))),
+        })
+    return inputs
+
+
+def cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inp, noise, ri, sn):
+    """The oracle (CPU restatement, kind 'port') on ONE utterance of the same workload."""
+    from oracle import flow as oflow, hift as ohift, llm as ollm, pipeline as opipe
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    PL = {k: v.cpu() for k, v in sd_llm.items()}
+    PF = {k: v.cpu() for k, v in sd_flow.items()}
+    PH = ohift.prepare({k: v.cpu().numpy() for k, v in sd_hift.items()})
+    t0 = time.time()
+    out = opipe.tts(inp, PL, PF, PH, cfg, noise.cpu(), ri.cpu(), sn.cpu(), min_len=N_TOK, max_len=N_TOK)
+    dt = time.time() - t0
+    audio = out["tts_speech"].shape[1] / 24000.0
+    return {"value": round(audio / dt, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
+            "sample": f"1 utterance of the same workload (5 s prompt, {N_TOK} forced tokens -> {audio:.1f} s audio) in {dt:.1f} s, "
+                      f"torch fp32 on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from fangyan_tts_amd import _lib, build, synth
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    from fangyan_tts_amd.spec import ModelCfg
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build(verbose=False)
+    cfg = ModelCfg()
+    sd_llm = synth.state_dict_torch(cfg.llm.manifest(), dev, skip=("lm_head",))
+    sd_flow = synth.state_dict_torch(cfg.flow.manifest(), dev)
+    sd_hift = synth.state_dict_torch(cfg.hift.manifest(), dev)
+    T = 2 * (P_TOK + N_TOK)
+    noise = torch.from_numpy(synth.flow_rand_noise(T)).to(dev)
+    ri = torch.from_numpy(synth.hift_rand_ini()).to(dev)
+    sn = torch.from_numpy(synth.hift_sine_noise(2 * N_TOK * 480)).to(dev)
+    model = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=BATCH, max_text=64, max_prompt_tokens=P_TOK,
+                            max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn)
+    inputs = make_inputs(cfg, rank)
+    forced = [N_TOK] * BATCH
+    gathered = torch.empty(world * BATCH, 2 * N_TOK * 480, device=dev) if world > 1 else None
+
+    def step():
+        wav, samples, _ = model.tts_batch(inputs, min_len=forced, max_len=forced, keep_on_device=True)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, wav)          # RCCL over xGMI: the finished audio of every rank
+        return samples
+
+    for _ in range(a.warmup):
+        samples = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        samples = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    audio_per_step = world * sum(samples) / 24000.0
+    value = audio_per_step * a.steps / dt
+
+    # roofline leg: one more step with HIP events around every launch of the dominant kernel
+    L = _lib.lib()
+    L.fy_prof_reset()
+    L.fy_prof_enable(1)
+    step()
+    torch.cuda.synchronize()
+    L.fy_prof_enable(0)
+    prof = {k: _lib.prof_get(k) for k in ("gemm_bf16", "conv_mfma", "gemv")}
+    L.fy_prof_reset()
+    ms, flops, n = prof["gemm_bf16"]
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    roofline = {"bound": "mfma", "kernel": "gemm_bf16_k<false> (DiT linears, 128x128x32 tile)", "achieved": round(achieved, 2),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "launches_per_step": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+                "gflop_per_launch": round(flops / max(n, 1) / 1e9, 3),
+                "stage_ms_per_step": {k: round(v[0], 3) for k, v in prof.items()}}
+
+    out = {
+        "metric": "synthesised audio sec/sec (RTF^-1) CosyVoice3-0.5B instruct, batch 8",
+        "value": round(value, 3), "unit": "audio_s/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "CosyVoice3-0.5B instruct (inference_instruct2), batch 8 mixed-length utterances per GPU, "
+                               "5 s prompt, 75 forced speech tokens (3 s) each, LM greedy -> 10-step CFG flow (DiT-22) -> HiFT",
+                   "batch_per_gpu": BATCH, "tokens_per_utt": N_TOK, "prompt_tokens": P_TOK, "parallelism": f"dp{world}",
+                   "weights": "random-init, CosyVoice3-0.5B shapes (859 M params)"},
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inputs[0], noise, ri, sn)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,10 @@ def check(rc: int):
 def _declare(L):
     vp, i32, u32, f32p, i32p = C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.POINTER(C.c_int32)
     L.fy_version.restype = C.c_int
+    L.fy_prof_enable.argtypes = [C.c_int]
+    L.fy_prof_enable.restype = None
+    L.fy_prof_reset.restype = None
+    L.fy_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.fy_hift_default_config.argtypes = [C.POINTER(HiftConfig)]
     L.fy_hift_default_config.restype = None
     L.fy_hift_create.argtypes = [C.POINTER(vp), C.POINTER(HiftConfig), C.POINTER(FyTensor), i32, i32, i32, vp]
@@ -114,3 +118,10 @@ def tensor_table(weights):
 
 def int_array(values):
     return (C.c_int32 * len(values))(*[int(v) for v in values])
+
+
+def prof_get(name: str):
+    """(total_ms, work, launches) of the profiled launches called `name`."""
+    ms, work, n = C.c_double(), C.c_double(), C.c_int64()
+    check(lib().fy_prof_get(name.encode(), C.byref(ms), C.byref(work), C.byref(n)))
+    return ms.value, work.value, n.value

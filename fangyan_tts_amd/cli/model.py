@@ -1,0 +1,96 @@
+"""Orchestrator with the reference's `CosyVoice3Model` surface
+(CosyVoice/cosyvoice/cli/model.py:324-441): tts(**model_input) -> generator of
+{'tts_speech': FloatTensor (1, S) on CPU}; plus `tts_batch`, the batched entry the
+reference lacks (it is strictly batch 1: flow/flow.py:369).
+
+All three stages run in libfy_cosy3 (HIP); this file only moves pointers around.
+"""
+from __future__ import annotations
+
+import threading
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import torch
+
+from ..flow import FlowEngine
+from ..hift import HiftEngine
+from ..llm import LlmEngine
+from ..spec import ModelCfg, SAMPLE_RATE
+
+
+class CosyVoice3Model:
+    def __init__(self, llm_weights: Dict[str, torch.Tensor], flow_weights: Dict[str, torch.Tensor],
+                 hift_weights: Dict[str, torch.Tensor], cfg: ModelCfg = ModelCfg(), device: Optional[torch.device] = None,
+                 max_batch: int = 8, max_text: int = 128, max_prompt_tokens: int = 800, max_tokens: int = 800,
+                 rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
+                 sine_noise: Optional[torch.Tensor] = None, fp16: bool = False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self.cfg, self.fp16 = cfg, fp16
+        self.max_batch, self.max_tokens, self.max_prompt_tokens = max_batch, max_tokens, max_prompt_tokens
+        max_frames = 2 * (max_tokens + max_prompt_tokens)
+        self.llm = LlmEngine(llm_weights, cfg.llm, max_batch=max_batch, max_ctx=2 + max_text + max_prompt_tokens + max_tokens,
+                             device=self.device)
+        self.flow = FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device)
+        self.hift = HiftEngine(hift_weights, cfg.hift, max_batch=max_batch, max_frames=2 * max_tokens, device=self.device)
+        # The reference draws these buffers once at construction and never stores them in a checkpoint
+        # (flow_matching.py:199-200; generator.py:223-226); pass them in to reproduce a given instance.
+        g = torch.Generator().manual_seed(0)
+        self.rand_noise = (rand_noise if rand_noise is not None else torch.randn(1, 80, max_frames, generator=g)).to(self.device)
+        self.rand_ini = (rand_ini if rand_ini is not None else torch.rand(1, 9, generator=g)).to(self.device)
+        n = 2 * max_tokens * cfg.hift.upsample_total
+        self.sine_noise = (sine_noise if sine_noise is not None else torch.rand(1, n, 9, generator=g)).to(self.device).contiguous()
+        self.token_hop_len = 25
+        self.lock = threading.Lock()          # the engines' handles are single-threaded
+
+    # ------------------------------------------------------------------ batched path
+    @torch.inference_mode()
+    def tts_batch(self, inputs: Sequence[Dict[str, torch.Tensor]], min_len: Optional[Sequence[int]] = None,
+                  max_len: Optional[Sequence[int]] = None, speed: float = 1.0, keep_on_device: bool = False):
+        """inputs: dicts with the reference's model_input keys (cli/frontend.py:168-213).
+        Returns (wav (B, Smax) fp32, n_samples list, tokens list)."""
+        B = len(inputs)
+        assert 1 <= B <= self.max_batch
+        z = torch.zeros(1, 0, dtype=torch.int32)
+        text = [d["text"].reshape(-1).tolist() for d in inputs]
+        ptext = [d.get("prompt_text", z).reshape(-1).tolist() for d in inputs]
+        pspeech = [d.get("llm_prompt_speech_token", z).reshape(-1).tolist() for d in inputs]
+        with self.lock:
+            out, out_n, _ = self.llm.generate(text, ptext, pspeech, min_len=min_len, max_len=max_len)
+            n_tok = out_n.cpu().tolist()
+            if min(n_tok) < 1:
+                raise RuntimeError("the language model emitted no speech token for an utterance")
+            fp = [d["flow_prompt_speech_token"].reshape(-1) for d in inputs]
+            pf = [d["prompt_speech_feat"].reshape(-1, 80) for d in inputs]
+            Pmax, PMmax = max(max(len(t) for t in fp), 1), max(max(f.shape[0] for f in pf), 1)
+            ptok = torch.zeros(B, Pmax, dtype=torch.int32)
+            pfeat = torch.zeros(B, PMmax, 80)
+            for b in range(B):
+                ptok[b, : len(fp[b])] = fp[b].to(torch.int32)
+                pfeat[b, : pf[b].shape[0]] = pf[b]
+            emb = torch.cat([d["flow_embedding"].reshape(1, -1) for d in inputs]).float()
+            mel = self.flow.inference(out, n_tok, ptok, [len(t) for t in fp], pfeat, [f.shape[0] for f in pf], emb, self.rand_noise)
+            frames = [2 * n for n in n_tok]
+            if speed != 1.0:                                    # cli/model.py:435-437
+                assert B == 1, "speed change only supports a single utterance"
+                mel = torch.nn.functional.interpolate(mel, size=int(mel.shape[2] / speed), mode="linear").contiguous()
+                frames = [mel.shape[2]]
+            wav, _ = self.hift.inference(mel, self.rand_ini, self.sine_noise, frames=frames)
+        samples = [f * self.cfg.hift.upsample_total for f in frames]
+        toks = [out[b, : n_tok[b]] for b in range(B)]
+        return (wav if keep_on_device else wav.cpu()), samples, toks
+
+    # ------------------------------------------------------------------ reference-shaped path
+    def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192), llm_embedding=torch.zeros(0, 192),
+            prompt_text=torch.zeros(1, 0, dtype=torch.int32), llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
+            flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32), prompt_speech_feat=torch.zeros(1, 0, 80),
+            source_speech_token=torch.zeros(1, 0, dtype=torch.int32), stream=False, speed=1.0, **kwargs):
+        if source_speech_token.shape[1] != 0:
+            raise NotImplementedError("voice conversion (inference_vc) is not part of this build")
+        if stream:
+            raise NotImplementedError("stream=True is not built yet (SURVEY 8 f3); use stream=False")
+        wav, samples, _ = self.tts_batch([dict(text=text, prompt_text=prompt_text, llm_prompt_speech_token=llm_prompt_speech_token,
+                                               flow_prompt_speech_token=flow_prompt_speech_token,
+                                               prompt_speech_feat=prompt_speech_feat, flow_embedding=flow_embedding)], speed=speed)
+        yield {"tts_speech": wav[:, : samples[0]]}

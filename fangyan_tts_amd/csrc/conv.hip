@@ -6,6 +6,7 @@
 // side, nearest-repeat upsample before the conv), ResBlock / Snake fusion points
 // from hifigan/generator.py:110-117, 682-700.
 #include "conv.h"
+#include "runtime.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
@@ -282,6 +283,7 @@ static int launch_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st) {
     int Cout_g = d.Cout / d.groups;
     dim3 grid(cdiv(d.L_out, TP), d.groups * cdiv(Cout_g, TCO), d.B);
     auto kern = conv1d_bf16_mfma_k<WP, WC, PR>;
+    ProfScope prof("conv_mfma", 2.0 * d.B * d.L_out * (double)d.Cout * (d.Cin / d.groups) * d.KW, st);
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(WP * WC * 64), lds, st, d, w.w_mfma, nrows_max);

@@ -460,7 +460,7 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
     // mel[b] = x[b][pmel:, :]^T in the reference's (B, 80, F) layout, flow.py:401
     for (int b = 0; b < B; ++b) {
         int F = 2 * n_token[b];
-        FY_TRY(transpose_blc_to_bcl(f->x + ((long)b * Tmax + n_pfeat[b]) * C, mel + (long)b * C * mel_frames, 1, C, F, 0, C, 0, st));
+        FY_TRY(transpose_blc_to_bcl(f->x + ((long)b * Tmax + n_pfeat[b]) * C, mel + (long)b * C * mel_frames, 1, C, F, 0, C, 0, mel_frames, st));
     }
     HIP_TRY(hipGetLastError());
     return FY_OK;
@@ -512,6 +512,6 @@ extern "C" int fy_dit_estimator(fy_flow* f, float* x, const float* mask, const f
     // a_in was written by rows of T (not f->Tmax): run the estimator with Tmax = T; h is overwritten only after a_in is complete
     HIP_TRY(hipStreamSynchronize(st));
     FY_TRY(dit_forward(f, B2, T, c.n_timesteps, (flags & FY_STREAMING) != 0, flags, st));
-    FY_TRY(transpose_blc_to_bcl(f->v, x, B2, C, T, (long)T * C, C, (long)C * T, st));
+    FY_TRY(transpose_blc_to_bcl(f->v, x, B2, C, T, (long)T * C, C, (long)C * T, T, st));
     return FY_OK;
 }

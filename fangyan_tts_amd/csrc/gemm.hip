@@ -1,5 +1,6 @@
 // See gemm.h.
 #include "gemm.h"
+#include "runtime.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
@@ -140,6 +141,7 @@ static int gemm_check(const void* A, int lda, const bf16_t* W, int M, int N, int
 int gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     FY_TRY(gemm_check(A, lda, W, M, N, K, epi, 2));
     dim3 grid(cdiv(N, GM_BN), cdiv(M, GM_BM));
+    ProfScope prof("gemm_bf16", 2.0 * M * N * K, st);
     hipLaunchKernelGGL(gemm_bf16_k<false>, grid, dim3(256), 0, st, (const void*)A, lda, W, M, N, K, epi);
     HIP_TRY(hipGetLastError());
     return FY_OK;
@@ -273,6 +275,7 @@ int gemv_bf16w(const GemvArgs& a, hipStream_t st) {
     FY_CHECK(ksplit == 1 || (a.partial && a.mode != GV_SWIGLU), FY_ERR_ARG, "gemv: split-K needs a workspace and a plain epilogue");
     FY_CHECK(a.mode != GV_SWIGLU || a.N % 8 == 0, FY_ERR_ARG, "gemv: SwiGLU rows must come in interleaved pairs");
     dim3 grid(cdiv(a.N, 4 * GV_ROWS), ksplit, cdiv(a.R, 8));
+    ProfScope prof("gemv", 2.0 * a.N * a.K, st);
     hipLaunchKernelGGL(gemv_bf16w_k, grid, dim3(256), (size_t)8 * kslice * sizeof(float), st, a, kslice, ksplit);
     if (ksplit > 1) hipLaunchKernelGGL(gemv_reduce_k, dim3(cdiv(a.R * a.N, 256)), dim3(256), 0, st, a, ksplit);
     HIP_TRY(hipGetLastError());

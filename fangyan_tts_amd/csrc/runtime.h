@@ -39,4 +39,13 @@ struct DevPool {
 
 // (B, C, L) -> (B, L, C) with per-batch strides in elements
 int transpose_bcl_to_blc(const float* src, float* dst, int B, int C, int L, long src_bs, long dst_bs, int dst_ld, hipStream_t st);
-int transpose_blc_to_bcl(const float* src, float* dst, int B, int C, int L, long src_bs, int src_ld, long dst_bs, hipStream_t st);
+int transpose_blc_to_bcl(const float* src, float* dst, int B, int C, int L, long src_bs, int src_ld, long dst_bs, int dst_ld, hipStream_t st);
+
+// ---- opt-in launch profiler (bench.py's roofline leg): brackets a launch with HIP events on the
+// ---- launch stream and accumulates per-name time and algorithmic work.  Off by default.
+struct ProfScope {
+    int slot = -1;
+    hipStream_t st;
+    ProfScope(const char* name, double work, hipStream_t st);
+    ~ProfScope();
+};

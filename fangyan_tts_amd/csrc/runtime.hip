@@ -60,7 +60,7 @@ __global__ void tr_bcl_blc_k(const float* __restrict__ src, float* __restrict__ 
         if (c < C && l < L) dst[b * dst_bs + (long)l * dst_ld + c] = tile[tx][i];
     }
 }
-__global__ void tr_blc_bcl_k(const float* __restrict__ src, float* __restrict__ dst, int C, int L, long src_bs, int src_ld, long dst_bs) {
+__global__ void tr_blc_bcl_k(const float* __restrict__ src, float* __restrict__ dst, int C, int L, long src_bs, int src_ld, long dst_bs, int dst_ld) {
     __shared__ float tile[32][33];
     int b = blockIdx.z, c0 = blockIdx.y * 32, l0 = blockIdx.x * 32;
     int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -71,7 +71,7 @@ __global__ void tr_blc_bcl_k(const float* __restrict__ src, float* __restrict__ 
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         int c = c0 + i, l = l0 + tx;
-        if (c < C && l < L) dst[b * dst_bs + (long)c * L + l] = tile[tx][i];
+        if (c < C && l < L) dst[b * dst_bs + (long)c * dst_ld + l] = tile[tx][i];
     }
 }
 
@@ -81,9 +81,56 @@ int transpose_bcl_to_blc(const float* src, float* dst, int B, int C, int L, long
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
-int transpose_blc_to_bcl(const float* src, float* dst, int B, int C, int L, long src_bs, int src_ld, long dst_bs, hipStream_t st) {
+int transpose_blc_to_bcl(const float* src, float* dst, int B, int C, int L, long src_bs, int src_ld, long dst_bs, int dst_ld, hipStream_t st) {
     dim3 grid(cdiv(L, 32), cdiv(C, 32), B);
-    hipLaunchKernelGGL(tr_blc_bcl_k, grid, dim3(256), 0, st, src, dst, C, L, src_bs, src_ld, dst_bs);
+    hipLaunchKernelGGL(tr_blc_bcl_k, grid, dim3(256), 0, st, src, dst, C, L, src_bs, src_ld, dst_bs, dst_ld);
     HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+#include <map>
+#include <mutex>
+struct ProfRec { std::string name; double work; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
+
+ProfScope::ProfScope(const char* name, double work, hipStream_t s) : st(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.name = name; r.work = work;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+    (void)hipEventRecord(r.a, st);
+    g_prof.push_back(r);
+    slot = (int)g_prof.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    (void)hipEventRecord(g_prof[slot].b, st);
+}
+
+extern "C" void fy_prof_enable(int on) { g_prof_on = on != 0; }
+
+extern "C" void fy_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof.clear();
+}
+
+// sums over all recorded launches called `name`: milliseconds, algorithmic work (flops or bytes), launches
+extern "C" int fy_prof_get(const char* name, double* total_ms, double* work, int64_t* count) {
+    FY_CHECK(name && total_ms && work && count, FY_ERR_ARG, "fy_prof_get: null argument");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    *total_ms = 0; *work = 0; *count = 0;
+    for (auto& r : g_prof) {
+        if (r.name != name) continue;
+        HIP_TRY(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        *total_ms += ms; *work += r.work; *count += 1;
+    }
     return FY_OK;
 }

@@ -32,6 +32,13 @@ typedef struct fy_tensor {
 const char* fy_last_error(void);
 int fy_version(void);
 
+/* ---- opt-in launch profiler: HIP events around the named kernels' launches, on their stream.
+ * names: "gemm_bf16" (DiT / projection GEMMs; work = flops), "conv_mfma" (work = flops),
+ * "gemv" (LLM decode products; work = weight bytes).  Adds two event records per launch while on. */
+void fy_prof_enable(int on);
+void fy_prof_reset(void);
+int fy_prof_get(const char* name, double* total_ms, double* work, int64_t* count);
+
 /* ---- flags ------------------------------------------------------------------ */
 #define FY_PRECISE 1u /* split-bf16 (hi+lo) activations on the MFMA paths: fp32-class accuracy, 2x MFMA work */
 #define FY_DIRECT 2u  /* HiFT / DiT position conv: run convolutions on the exact fp32 VALU kernel */

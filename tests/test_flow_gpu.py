@@ -23,8 +23,8 @@ DEV = torch.device("cuda:0")
 def make(cfg, max_batch=4, max_frames=320):
     from fangyan_tts_amd.flow import FlowEngine
     from oracle import flow as oflow
-    sd = synth.state_dict(cfg.manifest())
-    return FlowEngine(to_dev(sd, DEV), cfg, max_batch=max_batch, max_frames=max_frames), oflow.prepare(sd), oflow
+    sd = synth.state_dict_torch(cfg.manifest(), DEV)
+    return FlowEngine(sd, cfg, max_batch=max_batch, max_frames=max_frames), {k: v.cpu() for k, v in sd.items()}, oflow
 
 
 @pytest.fixture(scope="module")

@@ -40,10 +40,10 @@ def env():
     from fangyan_tts_amd.hift import HiftEngine
     from oracle import hift as ohift
     cfg = HiftCfg()
-    sd = synth.state_dict(cfg.manifest())
     dev = torch.device("cuda:0")
-    eng = HiftEngine({k: torch.from_numpy(v).to(dev) for k, v in sd.items()}, cfg, max_batch=4, max_frames=64)
-    P = ohift.prepare(sd)
+    sd = synth.state_dict_torch(cfg.manifest(), dev)
+    eng = HiftEngine(sd, cfg, max_batch=4, max_frames=64)
+    P = ohift.prepare({k: v.cpu().numpy() for k, v in sd.items()})
     ri = torch.from_numpy(synth.hift_rand_ini())
     sn = torch.from_numpy(synth.hift_sine_noise(64 * 480))
     return dict(cfg=cfg, eng=eng, P=P, o=ohift, dev=dev, ri=ri, sn=sn, ri_d=ri.to(dev), sn_d=sn.to(dev).contiguous())

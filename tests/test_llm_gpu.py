@@ -19,8 +19,8 @@ DEV = torch.device("cuda:0")
 
 def make(cfg, max_batch=4, max_ctx=512):
     from fangyan_tts_amd.llm import LlmEngine
-    sd = synth.state_dict(cfg.manifest(), skip=("lm_head",))
-    return LlmEngine(to_dev(sd, DEV), cfg, max_batch=max_batch, max_ctx=max_ctx)
+    sd = synth.state_dict_torch(cfg.manifest(), DEV, skip=("lm_head",))
+    return LlmEngine(sd, cfg, max_batch=max_batch, max_ctx=max_ctx)
 
 
 @pytest.fixture(scope="module")
