@@ -56,7 +56,8 @@ def make_inputs(cfg, rank):
 def cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inp, noise, ri, sn):
     """The oracle (CPU restatement, kind 'port') on ONE utterance of the same workload."""
     from oracle import flow as oflow, hift as ohift, llm as ollm, pipeline as opipe
-    cores = os.cpu_count() or 1
+    # the GPU box gives one job a 16-core share whatever os.cpu_count() says
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     PL = {k: v.cpu() for k, v in sd_llm.items()}
     PF = {k: v.cpu() for k, v in sd_flow.items()}
@@ -68,6 +69,10 @@ def cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inp, noise, ri, sn):
     return {"value": round(audio / dt, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
             "sample": f"1 utterance of the same workload (5 s prompt, {N_TOK} forced tokens -> {audio:.1f} s audio) in {dt:.1f} s, "
                       f"torch fp32 on {cores} threads"}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -94,6 +99,7 @@ def main():
     if not os.path.exists(_lib.LIB_PATH):
         build.build(verbose=False)
     cfg = ModelCfg()
+    log("generating synthetic weights on the GPU")
     sd_llm = synth.state_dict_torch(cfg.llm.manifest(), dev, skip=("lm_head",))
     sd_flow = synth.state_dict_torch(cfg.flow.manifest(), dev)
     sd_hift = synth.state_dict_torch(cfg.hift.manifest(), dev)
@@ -103,18 +109,21 @@ def main():
     sn = torch.from_numpy(synth.hift_sine_noise(2 * N_TOK * 480)).to(dev)
     model = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=BATCH, max_text=64, max_prompt_tokens=P_TOK,
                             max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn)
+    log("engines ready")
     inputs = make_inputs(cfg, rank)
     forced = [N_TOK] * BATCH
-    gathered = torch.empty(world * BATCH, 2 * N_TOK * 480, device=dev) if world > 1 else None
+    from fangyan_tts_amd.parallel import gather_audio
 
     def step():
         wav, samples, _ = model.tts_batch(inputs, min_len=forced, max_len=forced, keep_on_device=True)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, wav)          # RCCL over xGMI: the finished audio of every rank
+            gather_audio(wav, samples)          # RCCL over xGMI: the finished audio of every rank, on every rank
         return samples
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
         samples = step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -131,6 +140,7 @@ def main():
         dt = float(t.item())
     audio_per_step = world * sum(samples) / 24000.0
     value = audio_per_step * a.steps / dt
+    log(f"timed {a.steps} steps: {1e3 * dt / a.steps:.1f} ms/step, {value:.1f} audio_s/s")
 
     # roofline leg: one more step with HIP events around every launch of the dominant kernel
     L = _lib.lib()
@@ -161,6 +171,7 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log("timing the CPU oracle on one utterance")
         out["cpu_baseline"] = cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inputs[0], noise, ri, sn)
     if rank == 0:
         print(json.dumps(out))

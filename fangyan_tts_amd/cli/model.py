@@ -77,6 +77,7 @@ class CosyVoice3Model:
                 mel = torch.nn.functional.interpolate(mel, size=int(mel.shape[2] / speed), mode="linear").contiguous()
                 frames = [mel.shape[2]]
             wav, _ = self.hift.inference(mel, self.rand_ini, self.sine_noise, frames=frames)
+            self.last_mel, self.last_frames = mel, frames        # kept for parity tests / debugging
         samples = [f * self.cfg.hift.upsample_total for f in frames]
         toks = [out[b, : n_tok[b]] for b in range(B)]
         return (wav if keep_on_device else wav.cpu()), samples, toks
