@@ -196,3 +196,85 @@ int llm_attention(const float* q, int q_ld, const float* Kc, const float* Vc, co
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
+
+// -----------------------------------------------------------------------------------------------
+// Decode step: split-half RoPE of this row's q and new k, the cache append, and attention over
+// positions 0..pos in one launch.  qkv: fp32 [R][(Hq+2Hk)*64] raw projections of the current token;
+// the new key/value never round-trip through the cache inside the step (each block rotates its own
+// copy; the first query head of a kv group writes it for later steps).
+__global__ __launch_bounds__(64) void llm_attention_step_k(const float* __restrict__ qkv, float* __restrict__ Kc, float* __restrict__ Vc,
+                                                           const int* __restrict__ row_seq, const int* __restrict__ row_pos,
+                                                           const float* __restrict__ inv_freq, float* __restrict__ out, int o_ld,
+                                                           int Hq, int Hk, int max_ctx, float scale) {
+    extern __shared__ float sh[];             // [64] q + [max_ctx] scores
+    float* qs = sh;
+    float* sc = sh + 64;
+    const int r = blockIdx.x, hq = blockIdx.y, lane = threadIdx.x;
+    const int seq = row_seq[r], pos = row_pos[r];
+    const int grp = Hq / Hk, hk = hq / grp;
+    const int ld = (Hq + 2 * Hk) * 64;
+    const float* row = qkv + (long)r * ld;
+    const float ang = (float)pos * inv_freq[lane & 31];
+    const float cs = cosf(ang), sn = sinf(ang);
+    const float qv = row[hq * 64 + lane], kv = row[(Hq + hk) * 64 + lane], vv = row[(Hq + Hk + hk) * 64 + lane];
+    const float qo = __shfl_xor(qv, 32, 64), ko = __shfl_xor(kv, 32, 64);
+    const float qr = lane < 32 ? qv * cs - qo * sn : qv * cs + qo * sn;
+    const float kr = lane < 32 ? kv * cs - ko * sn : kv * cs + ko * sn;
+    float* Kb = Kc + ((long)seq * Hk + hk) * max_ctx * 64;
+    float* Vb = Vc + ((long)seq * Hk + hk) * max_ctx * 64;
+    if (hq % grp == 0) {
+        Kb[(long)pos * 64 + lane] = kr;
+        Vb[(long)pos * 64 + lane] = vv;
+    }
+    qs[lane] = qr;
+    __syncthreads();
+    const float s_new = wave_sum(qr * kr) * scale;
+    float mx = s_new;
+    for (int j = lane; j < pos; j += 64) {
+        const float4* kp = reinterpret_cast<const float4*>(Kb + (long)j * 64);
+        float s = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < 16; ++d4) {
+            float4 k4 = kp[d4];
+            s = fmaf(qs[d4 * 4 + 0], k4.x, s);
+            s = fmaf(qs[d4 * 4 + 1], k4.y, s);
+            s = fmaf(qs[d4 * 4 + 2], k4.z, s);
+            s = fmaf(qs[d4 * 4 + 3], k4.w, s);
+        }
+        s *= scale;
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < pos; j += 64) {
+        float p = expf(sc[j] - mx);
+        sc[j] = p;
+        sum += p;
+    }
+    const float p_new = expf(s_new - mx);
+    sum = wave_sum(sum) + p_new;
+    __syncthreads();
+    float acc = p_new * vv;
+    int j = 0;
+    for (; j + 4 <= pos; j += 4) {           // four independent loads in flight per trip
+        float v0 = Vb[(long)j * 64 + lane], v1 = Vb[(long)(j + 1) * 64 + lane], v2 = Vb[(long)(j + 2) * 64 + lane], v3 = Vb[(long)(j + 3) * 64 + lane];
+        acc = fmaf(sc[j], v0, acc);
+        acc = fmaf(sc[j + 1], v1, acc);
+        acc = fmaf(sc[j + 2], v2, acc);
+        acc = fmaf(sc[j + 3], v3, acc);
+    }
+    for (; j < pos; ++j) acc = fmaf(sc[j], Vb[(long)j * 64 + lane], acc);
+    out[(long)r * o_ld + hq * 64 + lane] = acc / sum;
+}
+
+int llm_attention_step(const float* qkv, float* Kc, float* Vc, const int* row_seq, const int* row_pos, const float* inv_freq,
+                       float* out, int o_ld, int R, int Hq, int Hk, int max_ctx, hipStream_t st) {
+    FY_CHECK(qkv && Kc && Vc && row_seq && row_pos && inv_freq && out && R >= 1 && Hq % Hk == 0, FY_ERR_ARG, "llm_attention_step: bad arguments");
+    size_t lds = (64 + (size_t)max_ctx) * sizeof(float);
+    FY_CHECK(lds <= 64 * 1024, FY_ERR_ARG, "llm_attention_step: context %d too long for the score buffer", max_ctx);
+    hipLaunchKernelGGL(llm_attention_step_k, dim3(R, Hq), dim3(64), lds, st, qkv, Kc, Vc, row_seq, row_pos, inv_freq, out, o_ld, Hq, Hk,
+                       max_ctx, 0.125f);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}

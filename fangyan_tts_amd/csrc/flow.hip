@@ -170,6 +170,10 @@ static int to_bf16(fy_flow* f, const float* src, size_t n, bf16_t** dst, hipStre
     FY_TRY(f->pool.alloc(dst, n));
     return cast_f32_bf16(src, *dst, n, st);
 }
+static int to_packed(fy_flow* f, const float* src, int N, int K, bf16_t** dst, hipStream_t st) {
+    FY_TRY(f->pool.alloc(dst, gemv_packed_elems(N, K)));
+    return gemv_pack(src, *dst, N, K, st);
+}
 static int copy_f32(fy_flow* f, const float* src, size_t n, float** dst, hipStream_t st) {
     FY_TRY(f->pool.alloc(dst, n));
     HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -262,11 +266,11 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
         GETW(ob, E + "proj_out.bias", C);
         GETW(fw, E + "norm_out.linear.weight", 2 * D, D);
         GETW(fb, E + "norm_out.linear.bias", 2 * D);
-        TRYC(to_bf16(f, t0w, (size_t)D * 256, &f->w_t0, st)); TRYC(copy_f32(f, t0b, D, &f->b_t0, st));
-        TRYC(to_bf16(f, t2w, (size_t)D * D, &f->w_t2, st)); TRYC(copy_f32(f, t2b, D, &f->b_t2, st));
+        TRYC(to_packed(f, t0w, D, 256, &f->w_t0, st)); TRYC(copy_f32(f, t0b, D, &f->b_t0, st));
+        TRYC(to_packed(f, t2w, D, D, &f->w_t2, st)); TRYC(copy_f32(f, t2b, D, &f->b_t2, st));
         TRYC(to_bf16(f, iw, (size_t)D * 4 * C, &f->w_in, st)); TRYC(copy_f32(f, ib, D, &f->b_in, st));
         TRYC(to_bf16(f, ow, (size_t)C * D, &f->w_out, st)); TRYC(copy_f32(f, ob, C, &f->b_out, st));
-        TRYC(to_bf16(f, fw, (size_t)2 * D * D, &f->w_fin, st)); TRYC(copy_f32(f, fb, 2 * D, &f->b_fin, st));
+        TRYC(to_packed(f, fw, 2 * D, D, &f->w_fin, st)); TRYC(copy_f32(f, fb, 2 * D, &f->b_fin, st));
         const int cg = D / c.conv_pos_groups;
         GETW(c1w, E + "input_embed.conv_pos_embed.conv1.0.weight", D, cg, c.conv_pos_k);
         GETW(c1b, E + "input_embed.conv_pos_embed.conv1.0.bias", D);
@@ -288,7 +292,7 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
         GETW(ow, b + "attn.to_out.0.weight", D, inner); GETW(ob, b + "attn.to_out.0.bias", D);
         GETW(f1w, b + "ff.ff.0.0.weight", FF, D); GETW(f1b, b + "ff.ff.0.0.bias", FF);
         GETW(f2w, b + "ff.ff.2.weight", D, FF); GETW(f2b, b + "ff.ff.2.bias", D);
-        TRYC(to_bf16(f, mw, (size_t)6 * D * D, &k.wmod, st)); TRYC(copy_f32(f, mb, 6 * D, &k.bmod, st));
+        TRYC(to_packed(f, mw, 6 * D, D, &k.wmod, st)); TRYC(copy_f32(f, mb, 6 * D, &k.bmod, st));
         TRYC(f->pool.alloc(&k.wqkv, (size_t)3 * inner * D));
         TRYC(f->pool.alloc(&k.bqkv, (size_t)3 * inner));
         const float* ws[3] = {qw, kw, vw};

@@ -29,17 +29,26 @@ int gemm_f32a_precise(const float* A, int lda, const bf16_t* W, int M, int N, in
 int cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
 
 // ---- decode-side products -----------------------------------------------------------
-enum { GV_STORE = 0, GV_ADD = 1, GV_SWIGLU = 2 };
+enum { GV_STORE = 0, GV_ADD = 1, GV_SWIGLU = 2, GV_SWIGLU_SPLIT = 3 };
 struct GemvArgs {
-    const bf16_t* W = nullptr;   // [N][K] row-major
-    const float* x = nullptr;    // [R][ldx]
+    const bf16_t* W = nullptr;   // packed by gemv_pack (B-fragment order of v_mfma_f32_32x32x16_bf16)
+    const float* x = nullptr;    // [R][ldx] fp32, K <= 1024 (split in LDS) ...
+    const bf16_t* x_split = nullptr; // ... or pre-split bf16 [ceil(R/8)][24][ldx] (hi / mid / lo planes of 8 rows), any K
     int ldx = 0;
     int R = 0, N = 0, K = 0;
     const float* bias = nullptr; // [N]
     float* y = nullptr;          // [R][ldy]
+    bf16_t* y_split = nullptr;   // GV_SWIGLU_SPLIT: [ceil(R/8)][24][ldy] planes for a following x_split product
     int ldy = 0;
     int mode = GV_STORE;         // GV_ADD: y += ; GV_SWIGLU: rows interleaved (gate_i, up_i) -> y[r][i] = silu(g)*u, N counts both
-    float* partial = nullptr;    // workspace [ksplit][R][N] when K is split
+    const float* norm_w = nullptr; // fused RMSNorm: y = W (norm_w * x) * rsqrt(mean(x^2) + eps), K <= 1024
+    float eps = 0.f;
+    float* partial = nullptr;    // split-K workspace of the pre-split form (gemv_partial_floats), with ...
+    int* counters = nullptr;     // ... zero-initialised arrival counters (gemv_counter_ints); both optional
 };
 int gemv_bf16w(const GemvArgs& a, hipStream_t st);
+// fp32 [N][K] row-major (torch Linear layout) -> bf16 fragment order; dst holds gemv_packed_elems(N, K) elements
+size_t gemv_packed_elems(int N, int K);
+int gemv_pack(const float* src, bf16_t* dst, int N, int K, hipStream_t st);
 size_t gemv_partial_floats(int R, int N, int K);
+size_t gemv_counter_ints(int R, int N, int K);

@@ -166,118 +166,294 @@ int cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st) {
 }
 
 // =============================================================================
-// decode GEMV: block = 4 waves x 4 output rows; lanes split K in 8-element chunks;
-// 8 activation rows staged in LDS as fp32; fp32 FMA on bf16 weights widened in registers.
+// decode GEMV on the matrix cores: y[r][n] = sum_k W[n][k] x[r][k] for up to 8 fp32 activation
+// rows per z-slice, at fp32 fidelity.
+//   * each activation is split exactly into three bf16 terms x = hi + mid + lo (3 x 8 mantissa bits);
+//     the 8 rows become 24 rows of the A operand of v_mfma_f32_32x32x16_bf16 (rows 0-7 hi, 8-15 mid,
+//     16-23 lo, 24-31 zero) and the three partial products are summed in the epilogue.  With
+//     bf16-representable weights every product is exact and the accumulation is fp32, so the result
+//     tracks an fp32 reference - which is what keeps greedy token ids bit-exact;
+//   * weights are pre-packed in B-fragment order [N/32][K/16][64 lanes][8], so a wave streams 1 KiB
+//     contiguous per MFMA with non-temporal loads and eight fragments in flight;
+//   * a block owns one 32-column tile; its waves split K and combine through LDS in a fixed order
+//     (deterministic: no atomics);  an optional RMSNorm is folded in (activations times the norm
+//     weight before the split, 1/rms on the finished sum).
 // =============================================================================
-#define GV_ROWS 4
-#define GV_KSLICE 1280       // activations staged per block: 8 x 1280 fp32 = 40 KB
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#define GV_SLICE 1024                      // K staged per pass
+#define GV_PITCH (GV_SLICE + 8)            // bf16 elements per LDS row
+#define GV_BATCH 8                         // weight fragments in flight per wave
 
-__global__ __launch_bounds__(256) void gemv_bf16w_k(GemvArgs a, int kslice, int ksplit) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];       // [8][kslice]
+__device__ __forceinline__ frag_ab ld_frag_nt(const bf16_t* p) {
+    u32x4_t r = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return __builtin_bit_cast(frag_ab, r);
+}
+
+// split one fp32 value exactly into three bf16 terms (hardware round-to-nearest-even converts)
+__device__ __forceinline__ void split3(float f, uint32_t& h, uint32_t& m, uint32_t& l) {
+    __bf16 hb = (__bf16)f;
+    float r1 = f - (float)hb;
+    __bf16 mb = (__bf16)r1;
+    float r2 = r1 - (float)mb;
+    __bf16 lb = (__bf16)r2;
+    h = __builtin_bit_cast(unsigned short, hb);
+    m = __builtin_bit_cast(unsigned short, mb);
+    l = __builtin_bit_cast(unsigned short, lb);
+}
+
+// shared epilogue of the two GEMV kernels (wave 0 of the block): p[i] is the finished sum for
+// activation row r = 4*kh + i, output column n.  yres[i]: the residual prefetched at kernel start.
+__device__ __forceinline__ void gv_epilogue(const GemvArgs& a, const float (&p)[4], const float (&yres)[4], const float* rstd_s,
+                                            int n, int kh, int lr, int R) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * kh + i;
+        float tot = p[i];
+        if (rstd_s) tot *= rstd_s[r];
+        if (a.bias && n < a.N) tot += a.bias[n];
+        const long rr = (long)blockIdx.z * 8 + r;
+        if (a.mode == GV_SWIGLU || a.mode == GV_SWIGLU_SPLIT) {
+            float other = __shfl_xor(tot, 1, 64);          // rows interleaved (gate_i, up_i)
+            if ((lr & 1) == 0 && r < R && n < a.N) {
+                float v = act_silu(tot) * other;
+                if (a.mode == GV_SWIGLU) a.y[rr * a.ldy + (n >> 1)] = v;
+                else {                                      // three bf16 planes for the direct-A consumer
+                    uint32_t h, m, l;
+                    split3(v, h, m, l);
+                    bf16_t* o = a.y_split + (long)blockIdx.z * 24 * a.ldy + (n >> 1);
+                    o[(long)r * a.ldy] = (bf16_t)h;
+                    o[(long)(8 + r) * a.ldy] = (bf16_t)m;
+                    o[(long)(16 + r) * a.ldy] = (bf16_t)l;
+                }
+            }
+        } else if (r < R && n < a.N) {
+            if (a.mode == GV_ADD) a.y[rr * a.ldy + n] = yres[i] + tot; else a.y[rr * a.ldy + n] = tot;
+        }
+    }
+}
+
+// (A) K <= 1024: activations staged (and split) through LDS; 4 waves split K.
+__global__ __launch_bounds__(256) void gemv_lds_k(GemvArgs a) {
+    constexpr int NW = 4, MAXF = GV_SLICE / 16 / NW;                        // <= 16 fragments per wave
+    extern __shared__ __attribute__((aligned(16))) char gv_smem[];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(gv_smem);                       // [24][GV_PITCH]
+    float* red = reinterpret_cast<float*>(gv_smem + 24 * GV_PITCH * 2);     // [NW][64][4]
+    float* rstd_s = red + NW * 256;                                         // [8]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int ks = blockIdx.y;
-    const int k0 = ks * kslice;
-    const int kn = min(kslice, a.K - k0);                              // multiple of 8
+    const int lr = lane & 31, kh = lane >> 5;
+    const int n32 = blockIdx.x, K16 = a.K / 16, n = n32 * 32 + lr;
     const float* xg = a.x + (long)blockIdx.z * 8 * a.ldx;
     const int R = min(8, a.R - blockIdx.z * 8);
-    for (int i = tid; i < 8 * (kn / 4); i += 256) {
-        int r = i / (kn / 4), c4 = (i % (kn / 4)) * 4;
-        float4 v = make_float4(0, 0, 0, 0);
-        if (r < R) v = *reinterpret_cast<const float4*>(xg + (long)r * a.ldx + k0 + c4);
-        *reinterpret_cast<float4*>(xs + r * kslice + c4) = v;
+    const bf16_t* wt = a.W + (long)n32 * K16 * 512 + lane * 8;
+    // everything that does not depend on the activations is requested first: this wave's weight
+    // fragments (kk = wid, wid+4, ...) and, for y += Wx, the residual
+    frag_ab b[MAXF];
+#pragma unroll
+    for (int u = 0; u < MAXF; ++u) {
+        const int kk = wid + u * NW;
+        if (kk < K16) b[u] = ld_frag_nt(wt + (long)kk * 512);
     }
-    __syncthreads();
-    const int n_first = (blockIdx.x * 4 + wid) * GV_ROWS;
-    if (n_first >= a.N) return;
-    float acc[GV_ROWS * 8];
+    float yres[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.mode == GV_ADD && wid == 0 && n < a.N) {
 #pragma unroll
-    for (int i = 0; i < GV_ROWS * 8; ++i) acc[i] = 0.f;
-    const int nchunk = kn / 8;
-    for (int c = lane; c < nchunk; c += 64) {
-        uint4 w[GV_ROWS];
+        for (int i = 0; i < 4; ++i)
+            if (4 * kh + i < R) yres[i] = a.y[((long)blockIdx.z * 8 + 4 * kh + i) * a.ldy + n];
+    }
+    {   // stage + split: 32 threads per activation row, each a fixed set of float4 columns (deterministic sums)
+        const int r = tid >> 5, q = tid & 31;
+        float4 v[GV_SLICE / 128];
 #pragma unroll
-        for (int j = 0; j < GV_ROWS; ++j) {
-            int n = min(n_first + j, a.N - 1);
-            w[j] = *reinterpret_cast<const uint4*>(a.W + (long)n * a.K + k0 + c * 8);
+        for (int i = 0; i < GV_SLICE / 128; ++i) {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i * 128 < a.K && r < R) v[i] = *reinterpret_cast<const float4*>(xg + (long)r * a.ldx + (q + 32 * i) * 4);
         }
+        float ss = 0.f;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            float4 x0 = *reinterpret_cast<const float4*>(xs + r * kslice + c * 8);
-            float4 x1 = *reinterpret_cast<const float4*>(xs + r * kslice + c * 8 + 4);
-#pragma unroll
-            for (int j = 0; j < GV_ROWS; ++j) {
-                float s = acc[j * 8 + r];
-                s = fmaf(__uint_as_float(w[j].x << 16), x0.x, s);
-                s = fmaf(__uint_as_float(w[j].x & 0xFFFF0000u), x0.y, s);
-                s = fmaf(__uint_as_float(w[j].y << 16), x0.z, s);
-                s = fmaf(__uint_as_float(w[j].y & 0xFFFF0000u), x0.w, s);
-                s = fmaf(__uint_as_float(w[j].z << 16), x1.x, s);
-                s = fmaf(__uint_as_float(w[j].z & 0xFFFF0000u), x1.y, s);
-                s = fmaf(__uint_as_float(w[j].w << 16), x1.z, s);
-                s = fmaf(__uint_as_float(w[j].w & 0xFFFF0000u), x1.w, s);
-                acc[j * 8 + r] = s;
+        for (int i = 0; i < GV_SLICE / 128; ++i) {
+            if (i * 128 < a.K) {
+                const int c4 = (q + 32 * i) * 4;
+                float4 x = v[i];
+                if (a.norm_w) {
+                    float4 w4 = *reinterpret_cast<const float4*>(a.norm_w + c4);
+                    ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+                    x.x *= w4.x; x.y *= w4.y; x.z *= w4.z; x.w *= w4.w;
+                }
+                uint32_t h[4], m[4], l[4];
+                split3(x.x, h[0], m[0], l[0]); split3(x.y, h[1], m[1], l[1]);
+                split3(x.z, h[2], m[2], l[2]); split3(x.w, h[3], m[3], l[3]);
+                *reinterpret_cast<uint2*>(xs + r * GV_PITCH + c4) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+                *reinterpret_cast<uint2*>(xs + (8 + r) * GV_PITCH + c4) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+                *reinterpret_cast<uint2*>(xs + (16 + r) * GV_PITCH + c4) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
             }
         }
-    }
-    // transpose-reduce the 32 per-lane partials over the 64 lanes: 32 shuffles instead of 32 x 6
+        if (a.norm_w) {
 #pragma unroll
-    for (int half = 16, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
-        const bool up = (lane & bit) != 0;
-#pragma unroll
-        for (int i = 0; i < half; ++i) {
-            float keep = up ? acc[i + half] : acc[i];
-            float send = up ? acc[i] : acc[i + half];
-            acc[i] = keep + __shfl_xor(send, bit, 64);
+            for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+            if (q == 0) rstd_s[r] = rsqrtf(ss / a.K + a.eps);
         }
     }
-    float tot = acc[0] + __shfl_xor(acc[0], 1, 64);
-    if (lane & 1) return;
-    const int v = lane >> 1, j = v >> 3, r = v & 7;
-    const int n = n_first + j;
-    if (n >= a.N || r >= R) return;
-    const long rr = (long)blockIdx.z * 8 + r;
-    if (ksplit > 1) {
-        a.partial[((long)ks * a.R + rr) * a.N + n] = tot;
-        return;
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    frag_ab zero_frag;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero_frag[e] = (__bf16)0.f;
+#pragma unroll
+    for (int u = 0; u < MAXF; ++u) {
+        const int kk = wid + u * NW;
+        if (kk < K16) {
+            frag_ab af = zero_frag;
+            if (lr < 24) af = *reinterpret_cast<const frag_ab*>(xs + lr * GV_PITCH + kk * 16 + kh * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b[u], acc, 0, 0, 0);
+        }
     }
-    if (a.bias) tot += a.bias[n];
-    if (a.mode == GV_SWIGLU) {
-        // rows interleaved (gate_i, up_i): the pair sits in lanes v and v + 8 (j even / j + 1)
-        float other = __shfl(tot, lane + 16, 64);
-        if ((j & 1) == 0) a.y[rr * a.ldy + (n >> 1)] = act_silu(tot) * other;
-    } else if (a.mode == GV_ADD) {
-        a.y[rr * a.ldy + n] += tot;
-    } else {
-        a.y[rr * a.ldy + n] = tot;
+    // D rows: reg i -> row (i&3) + 8*(i>>2) + 4*kh.  hi rows 0-7, mid 8-15, lo 16-23: activation row r = 4*kh + i
+    float p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = (acc[i] + acc[4 + i]) + acc[8 + i];
+    *reinterpret_cast<float4*>(red + (wid * 64 + lane) * 4) = make_float4(p[0], p[1], p[2], p[3]);
+    __syncthreads();
+    if (wid != 0) return;
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        float4 q = *reinterpret_cast<const float4*>(red + (w * 64 + lane) * 4);
+        p[0] += q.x; p[1] += q.y; p[2] += q.z; p[3] += q.w;
+    }
+    gv_epilogue(a, p, yres, a.norm_w ? rstd_s : nullptr, n, kh, lr, R);
+}
+
+// (B) any K: the A operand comes pre-split from global memory (x_split: bf16 [z][24][lda], written by a
+// GV_SWIGLU_SPLIT epilogue); no LDS staging, no slices.  K is split over gridDim.y blocks (more CUs
+// streaming the same few output tiles) and over the 16 waves of a block; the K-slice blocks of a tile
+// hand their partial sums over in HBM and the last one to arrive adds them in slice order, so the
+// result does not depend on arrival order (agent-scope release / acquire around an arrival ticket).
+__global__ __launch_bounds__(1024) void gemv_direct_k(GemvArgs a) {
+    constexpr int NW = 16;
+    __shared__ __attribute__((aligned(16))) float red[NW * 256];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int lr = lane & 31, kh = lane >> 5;
+    const int n32 = blockIdx.x, K16 = a.K / 16, n = n32 * 32 + lr;
+    const int KS = gridDim.y, ks = blockIdx.y;
+    const int kper = (K16 + KS - 1) / KS, kbeg = ks * kper, kend = min(K16, kbeg + kper);
+    const int R = min(8, a.R - blockIdx.z * 8);
+    const bf16_t* wt = a.W + (long)n32 * K16 * 512 + lane * 8;
+    const bf16_t* xa = a.x_split + ((long)blockIdx.z * 24 + min(lr, 23)) * a.ldx + kh * 8;
+    float yres[4] = {0.f, 0.f, 0.f, 0.f};
+    if (a.mode == GV_ADD && wid == 0 && n < a.N) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * kh + i < R) yres[i] = a.y[((long)blockIdx.z * 8 + 4 * kh + i) * a.ldy + n];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    frag_ab zero_frag;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero_frag[e] = (__bf16)0.f;
+    constexpr int DB = 8;                                  // fragments in flight per wave
+    for (int kb = kbeg + wid; kb < kend; kb += NW * DB) {
+        frag_ab b[DB], af[DB];
+#pragma unroll
+        for (int u = 0; u < DB; ++u) {
+            const int kk = kb + u * NW;
+            if (kk < kend) {
+                b[u] = ld_frag_nt(wt + (long)kk * 512);
+                af[u] = *reinterpret_cast<const frag_ab*>(xa + kk * 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < DB; ++u) {
+            const int kk = kb + u * NW;
+            if (kk < kend) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lr < 24 ? af[u] : zero_frag, b[u], acc, 0, 0, 0);
+        }
+    }
+    float p[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) p[i] = (acc[i] + acc[4 + i]) + acc[8 + i];
+    *reinterpret_cast<float4*>(red + (wid * 64 + lane) * 4) = make_float4(p[0], p[1], p[2], p[3]);
+    __syncthreads();
+    if (wid != 0) return;
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        float4 q = *reinterpret_cast<const float4*>(red + (w * 64 + lane) * 4);
+        p[0] += q.x; p[1] += q.y; p[2] += q.z; p[3] += q.w;
+    }
+    if (KS > 1) {
+        const long tile = (long)blockIdx.z * gridDim.x + n32;
+        float* slab = a.partial + (tile * KS) * 256;
+        *reinterpret_cast<float4*>(slab + (long)ks * 256 + lane * 4) = make_float4(p[0], p[1], p[2], p[3]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int ticket = 0;
+        if (lane == 0) ticket = __hip_atomic_fetch_add(a.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __shfl(ticket, 0, 64);
+        if (ticket != KS - 1) return;                       // not the last slice of this tile
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) a.counters[tile] = 0;                // ready for the next launch
+        p[0] = p[1] = p[2] = p[3] = 0.f;
+        for (int s2 = 0; s2 < KS; ++s2) {                   // fixed order: independent of who arrived when
+            float4 q = *reinterpret_cast<const float4*>(slab + (long)s2 * 256 + lane * 4);
+            p[0] += q.x; p[1] += q.y; p[2] += q.z; p[3] += q.w;
+        }
+    }
+    gv_epilogue(a, p, yres, nullptr, n, kh, lr, R);
+}
+
+// pack fp32 [N][K] (row-major, torch Linear layout) into B-fragment order, zero-padding N to 32
+__global__ void gemv_pack_k(const float* __restrict__ src, bf16_t* __restrict__ dst, int N, int K) {
+    const int K16 = K / 16;
+    const long total = (long)((N + 31) / 32) * K16 * 512;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int j = i & 7, l = (i >> 3) & 63;
+        const long f = i >> 9;
+        const int k16 = (int)(f % K16), n32 = (int)(f / K16);
+        const int n = n32 * 32 + (l & 31), k = k16 * 16 + 8 * (l >> 5) + j;
+        dst[i] = n < N ? f32_to_bf16(src[(long)n * K + k]) : (bf16_t)0;
     }
 }
 
-__global__ void gemv_reduce_k(GemvArgs a, int ksplit) {
-    long i = blockIdx.x * 256L + threadIdx.x;
-    if (i >= (long)a.R * a.N) return;
-    int n = (int)(i % a.N);
-    long r = i / a.N;
-    float s = 0.f;
-    for (int k = 0; k < ksplit; ++k) s += a.partial[((long)k * a.R + r) * a.N + n];
-    if (a.bias) s += a.bias[n];
-    if (a.mode == GV_ADD) a.y[r * a.ldy + n] += s; else a.y[r * a.ldy + n] = s;
+size_t gemv_packed_elems(int N, int K) { return (size_t)((N + 31) / 32) * (K / 16) * 512; }
+
+int gemv_pack(const float* src, bf16_t* dst, int N, int K, hipStream_t st) {
+    FY_CHECK(src && dst && N >= 1 && K >= 16 && K % 16 == 0, FY_ERR_ARG, "gemv_pack: bad shape N %d K %d", N, K);
+    size_t blocks = (gemv_packed_elems(N, K) + 255) / 256;
+    hipLaunchKernelGGL(gemv_pack_k, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, st, src, dst, N, K);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
 }
 
-static int gv_ksplit(int K) { return (K + GV_KSLICE - 1) / GV_KSLICE; }
-size_t gemv_partial_floats(int R, int N, int K) { return gv_ksplit(K) > 1 ? (size_t)gv_ksplit(K) * R * N : 0; }
+// split-K workspace of the direct form: [tiles][4 slices][64 lanes][4] floats and one arrival counter per tile
+size_t gemv_partial_floats(int R, int N, int K) { return K >= 2048 ? (size_t)cdiv(R, 8) * cdiv(N, 32) * 4 * 256 : 0; }
+size_t gemv_counter_ints(int R, int N, int K) { return K >= 2048 ? (size_t)cdiv(R, 8) * cdiv(N, 32) : 0; }
 
 int gemv_bf16w(const GemvArgs& a, hipStream_t st) {
-    FY_CHECK(a.W && a.x && a.y && a.R >= 1 && a.N >= 1 && a.K >= 8 && a.K % 8 == 0 && a.ldx % 4 == 0, FY_ERR_ARG,
+    FY_CHECK(a.W && (a.x || a.x_split) && (a.y || a.y_split) && a.R >= 1 && a.N >= 1 && a.K >= 16 && a.K % 16 == 0, FY_ERR_ARG,
              "gemv: bad arguments R %d N %d K %d", a.R, a.N, a.K);
-    int ksplit = gv_ksplit(a.K);
-    int kslice = ksplit == 1 ? a.K : ((a.K / ksplit + 7) / 8) * 8;
-    while (kslice * ksplit < a.K) kslice += 8;
-    FY_CHECK(ksplit == 1 || (a.partial && a.mode != GV_SWIGLU), FY_ERR_ARG, "gemv: split-K needs a workspace and a plain epilogue");
-    FY_CHECK(a.mode != GV_SWIGLU || a.N % 8 == 0, FY_ERR_ARG, "gemv: SwiGLU rows must come in interleaved pairs");
-    dim3 grid(cdiv(a.N, 4 * GV_ROWS), ksplit, cdiv(a.R, 8));
+    FY_CHECK(a.mode != GV_SWIGLU_SPLIT || a.y_split, FY_ERR_ARG, "gemv: GV_SWIGLU_SPLIT needs y_split");
+    FY_CHECK((a.mode != GV_SWIGLU && a.mode != GV_SWIGLU_SPLIT) || a.N % 2 == 0, FY_ERR_ARG, "gemv: SwiGLU rows must come in interleaved pairs");
+    FY_CHECK(((uintptr_t)a.W & 15) == 0, FY_ERR_ARG, "gemv: weights must be 16-B aligned");
+    dim3 grid(cdiv(a.N, 32), 1, cdiv(a.R, 8));
     ProfScope prof("gemv", 2.0 * a.N * a.K, st);
-    hipLaunchKernelGGL(gemv_bf16w_k, grid, dim3(256), (size_t)8 * kslice * sizeof(float), st, a, kslice, ksplit);
-    if (ksplit > 1) hipLaunchKernelGGL(gemv_reduce_k, dim3(cdiv(a.R * a.N, 256)), dim3(256), 0, st, a, ksplit);
+    if (a.x_split) {
+        FY_CHECK(!a.norm_w && a.ldx % 8 == 0 && ((uintptr_t)a.x_split & 15) == 0, FY_ERR_ARG, "gemv: bad pre-split operand");
+        int KS = (a.K >= 2048 && a.partial && a.counters) ? 4 : 1;
+        grid.y = KS;
+        hipLaunchKernelGGL(gemv_direct_k, grid, dim3(1024), 0, st, a);
+    } else {
+        FY_CHECK(a.K <= GV_SLICE && a.K % 128 == 0 && a.ldx % 4 == 0 && ((uintptr_t)a.x & 15) == 0, FY_ERR_ARG,
+                 "gemv: the LDS-staged form needs K <= %d, K %% 128 == 0 (K = %d)", GV_SLICE, a.K);
+        static bool attr_set = false;
+        const size_t lds = (size_t)24 * GV_PITCH * 2 + 4 * 256 * 4 + 8 * 4;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute((const void*)gemv_lds_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gemv_lds_k, grid, dim3(256), lds, st, a);
+    }
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }

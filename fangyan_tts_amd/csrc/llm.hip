@@ -28,9 +28,11 @@ struct fy_llm {
     bf16_t *w_head = nullptr, *embed_tokens = nullptr;
     float *Kc = nullptr, *Vc = nullptr;            // [layers][max_batch][kv_heads][max_ctx][64]
     float *h, *xn, *qkv, *ao, *act, *hb, *logits, *partial, *logp_keep;
+    bf16_t* act_split = nullptr;                     // SwiGLU output as three bf16 planes per 8 rows: [rows/8][24][inter]
     int *row_seq, *row_pos, *row_src, *last_row;
     int *st;                                          // [8][max_batch]: pos, raw_n, n_out, done, run, min_len, max_len, (spare)
     int *seq_ids;                                     // 0..max_batch-1
+    int *counters = nullptr;                          // split-K arrival counters of the down projection
     int B = 0;
     int n_speech() const { return cfg.speech_tokens + 200; }
     int qkv_dim() const { return (cfg.q_heads + 2 * cfg.kv_heads) * cfg.head_dim; }
@@ -163,6 +165,11 @@ static int to_bf16(fy_llm* l, const float* src, size_t n, bf16_t** dst, hipStrea
     FY_TRY(l->pool.alloc(dst, n));
     return cast_f32_bf16(src, *dst, n, st);
 }
+// fp32 [N][K] -> the GEMV's fragment-ordered bf16
+static int to_packed(fy_llm* l, const float* src, int N, int K, bf16_t** dst, hipStream_t st) {
+    FY_TRY(l->pool.alloc(dst, gemv_packed_elems(N, K)));
+    return gemv_pack(src, *dst, N, K, st);
+}
 static int copy_f32(fy_llm* l, const float* src, size_t n, float** dst, hipStream_t st) {
     FY_TRY(l->pool.alloc(dst, n));
     HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -170,13 +177,13 @@ static int copy_f32(fy_llm* l, const float* src, size_t n, float** dst, hipStrea
 }
 
 // rows (gate_i, up_i) interleaved so one wave owns both halves of a SwiGLU pair
-__global__ void interleave_gu_k(const float* __restrict__ g, const float* __restrict__ u, bf16_t* __restrict__ out, int inter, int H) {
+__global__ void interleave_gu_k(const float* __restrict__ g, const float* __restrict__ u, float* __restrict__ out, int inter, int H) {
     long n = (long)2 * inter * H;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         long row = i / H;
         int c = (int)(i % H);
         const float* src = (row & 1) ? u : g;
-        out[i] = f32_to_bf16(src[(row >> 1) * H + c]);
+        out[i] = src[(row >> 1) * H + c];
     }
 }
 
@@ -211,21 +218,26 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
         GETW(gw, p + "mlp.gate_proj.weight", I, H); GETW(uw, p + "mlp.up_proj.weight", I, H);
         GETW(dw, p + "mlp.down_proj.weight", H, I);
         GETW(n1, p + "input_layernorm.weight", H); GETW(n2, p + "post_attention_layernorm.weight", H);
-        TRYC(l->pool.alloc(&k.wqkv, (size_t)(Q + 2 * KV) * H));
+        // q, k, v rows concatenated; gate / up rows interleaved; all in the GEMV's fragment order
+        float* tmp = nullptr;
         TRYC(l->pool.alloc(&k.bqkv, (size_t)(Q + 2 * KV)));
-        TRYC(cast_f32_bf16(qw, k.wqkv, (size_t)Q * H, st));
-        TRYC(cast_f32_bf16(kw, k.wqkv + (size_t)Q * H, (size_t)KV * H, st));
-        TRYC(cast_f32_bf16(vw, k.wqkv + (size_t)(Q + KV) * H, (size_t)KV * H, st));
-        if (hipMemcpyAsync(k.bqkv, qb, Q * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(k.bqkv + Q, kb, KV * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
-            hipMemcpyAsync(k.bqkv + Q + KV, vb, KV * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-            fy_set_error("fy_llm_create: bias copy failed");
-            return fail(FY_ERR_HIP);
+        if (hipMalloc(&tmp, (size_t)2 * I * H * sizeof(float)) != hipSuccess) { fy_set_error("fy_llm_create: out of memory"); return fail(FY_ERR_HIP); }
+        bool ok = hipMemcpyAsync(tmp, qw, (size_t)Q * H * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                  hipMemcpyAsync(tmp + (size_t)Q * H, kw, (size_t)KV * H * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                  hipMemcpyAsync(tmp + (size_t)(Q + KV) * H, vw, (size_t)KV * H * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                  hipMemcpyAsync(k.bqkv, qb, Q * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                  hipMemcpyAsync(k.bqkv + Q, kb, KV * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                  hipMemcpyAsync(k.bqkv + Q + KV, vb, KV * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess;
+        int rc2 = ok ? to_packed(l, tmp, Q + 2 * KV, H, &k.wqkv, st) : FY_ERR_HIP;
+        if (rc2 == FY_OK) {
+            hipLaunchKernelGGL(interleave_gu_k, dim3(4096), dim3(256), 0, st, gw, uw, tmp, I, H);
+            rc2 = to_packed(l, tmp, 2 * I, H, &k.wgu, st);
         }
-        TRYC(to_bf16(l, ow, (size_t)H * Q, &k.wo, st));
-        TRYC(l->pool.alloc(&k.wgu, (size_t)2 * I * H));
-        hipLaunchKernelGGL(interleave_gu_k, dim3(4096), dim3(256), 0, st, gw, uw, k.wgu, I, H);
-        TRYC(to_bf16(l, dw, (size_t)H * I, &k.wd, st));
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(tmp);
+        if (rc2 != FY_OK) { if (!ok) fy_set_error("fy_llm_create: weight copy failed"); return fail(rc2); }
+        TRYC(to_packed(l, ow, H, Q, &k.wo, st));
+        TRYC(to_packed(l, dw, H, I, &k.wd, st));
         TRYC(copy_f32(l, n1, H, &k.ln1, st)); TRYC(copy_f32(l, n2, H, &k.ln2, st));
     }
     {
@@ -234,7 +246,7 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
         GETW(sw, "speech_embedding.weight", NS, H);
         GETW(ew, P + "embed_tokens.weight", c.vocab, H);
         TRYC(copy_f32(l, nw, H, &l->norm_w, st));
-        TRYC(to_bf16(l, hw, (size_t)NS * H, &l->w_head, st));
+        TRYC(to_packed(l, hw, NS, H, &l->w_head, st));
         TRYC(copy_f32(l, sw, (size_t)NS * H, &l->speech_emb, st));
         TRYC(to_bf16(l, ew, (size_t)c.vocab * H, &l->embed_tokens, st));
     }
@@ -252,8 +264,10 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
     TRYC(l->pool.alloc(&l->Kc, (size_t)c.layers * l->cache_layer()));
     TRYC(l->pool.alloc(&l->Vc, (size_t)c.layers * l->cache_layer()));
     TRYC(l->pool.alloc(&l->h, R * H)); TRYC(l->pool.alloc(&l->xn, R * H)); TRYC(l->pool.alloc(&l->qkv, R * l->qkv_dim()));
-    TRYC(l->pool.alloc(&l->ao, R * H)); TRYC(l->pool.alloc(&l->act, R * I)); TRYC(l->pool.alloc(&l->hb, B * H));
+    TRYC(l->pool.alloc(&l->ao, R * H)); TRYC(l->pool.alloc(&l->act, (size_t)16)); TRYC(l->pool.alloc(&l->act_split, ((R + 7) / 8) * 24 * (size_t)I)); TRYC(l->pool.alloc(&l->hb, B * H));
     TRYC(l->pool.alloc(&l->logits, B * NS)); TRYC(l->pool.alloc(&l->partial, gemv_partial_floats((int)R, H, I) + 16));
+    TRYC(l->pool.alloc(&l->counters, gemv_counter_ints((int)R, H, I) + 16));
+    if (hipMemsetAsync(l->counters, 0, (gemv_counter_ints((int)R, H, I) + 16) * sizeof(int), st) != hipSuccess) { fy_set_error("fy_llm_create: memset failed"); return fail(FY_ERR_HIP); }
     TRYC(l->pool.alloc(&l->logp_keep, (size_t)FY_LLM_KEEP_LOGP * B * NS));
     TRYC(l->pool.alloc(&l->row_seq, R)); TRYC(l->pool.alloc(&l->row_pos, R)); TRYC(l->pool.alloc(&l->row_src, R));
     TRYC(l->pool.alloc(&l->last_row, B)); TRYC(l->pool.alloc(&l->st, 8 * B)); TRYC(l->pool.alloc(&l->seq_ids, B));
@@ -276,28 +290,34 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
 extern "C" void fy_llm_destroy(fy_llm* l) { delete l; }
 
 // ---- forward over R rows (prefill rows or one decode row per sequence) ---------------------------------------------
-static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, hipStream_t st) {
+static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, bool decode, hipStream_t st) {
     const fy_llm_config& c = l->cfg;
     const int H = c.hidden, I = c.inter, QKV = l->qkv_dim();
     for (int i = 0; i < c.layers; ++i) {
         const LlmLayerW& k = l->L[i];
         float* Kc = l->Kc + (size_t)i * l->cache_layer();
         float* Vc = l->Vc + (size_t)i * l->cache_layer();
-        hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln1, l->xn, R, H, c.rms_eps);
-        GemvArgs a;
-        a.W = k.wqkv; a.x = l->xn; a.ldx = H; a.R = R; a.N = QKV; a.K = H; a.bias = k.bqkv; a.y = l->qkv; a.ldy = QKV;
+        GemvArgs a;          // input RMSNorm fused into the projection
+        a.W = k.wqkv; a.x = l->h; a.ldx = H; a.R = R; a.N = QKV; a.K = H; a.bias = k.bqkv; a.y = l->qkv; a.ldy = QKV;
+        a.norm_w = k.ln1; a.eps = c.rms_eps;
         FY_TRY(gemv_bf16w(a, st));
-        hipLaunchKernelGGL(rope_kv_k, dim3(R), dim3(256), 0, st, l->qkv, Kc, Vc, row_seq, row_pos, l->inv_freq, c.q_heads, c.kv_heads, l->max_ctx);
-        FY_TRY(llm_attention(l->qkv, QKV, Kc, Vc, row_seq, row_pos, l->ao, H, R, c.q_heads, c.kv_heads, l->max_ctx, st));
+        if (decode) {
+            FY_TRY(llm_attention_step(l->qkv, Kc, Vc, row_seq, row_pos, l->inv_freq, l->ao, H, R, c.q_heads, c.kv_heads, l->max_ctx, st));
+        } else {
+            // prefill: every row's key must be in the cache before any row attends
+            hipLaunchKernelGGL(rope_kv_k, dim3(R), dim3(256), 0, st, l->qkv, Kc, Vc, row_seq, row_pos, l->inv_freq, c.q_heads, c.kv_heads, l->max_ctx);
+            FY_TRY(llm_attention(l->qkv, QKV, Kc, Vc, row_seq, row_pos, l->ao, H, R, c.q_heads, c.kv_heads, l->max_ctx, st));
+        }
         GemvArgs o;
         o.W = k.wo; o.x = l->ao; o.ldx = H; o.R = R; o.N = H; o.K = H; o.y = l->h; o.ldy = H; o.mode = GV_ADD;
         FY_TRY(gemv_bf16w(o, st));
-        hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln2, l->xn, R, H, c.rms_eps);
-        GemvArgs g;
-        g.W = k.wgu; g.x = l->xn; g.ldx = H; g.R = R; g.N = 2 * I; g.K = H; g.y = l->act; g.ldy = I; g.mode = GV_SWIGLU;
+        GemvArgs g;          // post-attention RMSNorm fused
+        g.W = k.wgu; g.x = l->h; g.ldx = H; g.R = R; g.N = 2 * I; g.K = H; g.y_split = l->act_split; g.ldy = I; g.mode = GV_SWIGLU_SPLIT;
+        g.norm_w = k.ln2; g.eps = c.rms_eps;
         FY_TRY(gemv_bf16w(g, st));
-        GemvArgs d;
-        d.W = k.wd; d.x = l->act; d.ldx = I; d.R = R; d.N = H; d.K = I; d.y = l->h; d.ldy = H; d.mode = GV_ADD; d.partial = l->partial;
+        GemvArgs d;          // K = inter is too long to stage: the A operand arrives pre-split from the SwiGLU epilogue
+        d.W = k.wd; d.x_split = l->act_split; d.ldx = I; d.R = R; d.N = H; d.K = I; d.y = l->h; d.ldy = H; d.mode = GV_ADD;
+        d.partial = l->partial; d.counters = l->counters;
         FY_TRY(gemv_bf16w(d, st));
     }
     HIP_TRY(hipGetLastError());
@@ -307,9 +327,9 @@ static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, 
 static int llm_head_and_sample(fy_llm* l, int B, const float* rows, int32_t* out_ids, int out_ld, int keep_step, hipStream_t st) {
     const fy_llm_config& c = l->cfg;
     const int H = c.hidden, NS = l->n_speech();
-    hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(B, 4)), dim3(256), 0, st, rows, l->norm_w, l->xn, B, H, c.rms_eps);
-    GemvArgs a;
-    a.W = l->w_head; a.x = l->xn; a.ldx = H; a.R = B; a.N = NS; a.K = H; a.y = l->logits; a.ldy = NS;
+    GemvArgs a;              // final RMSNorm fused into the llm_decoder product
+    a.W = l->w_head; a.x = rows; a.ldx = H; a.R = B; a.N = NS; a.K = H; a.y = l->logits; a.ldy = NS;
+    a.norm_w = l->norm_w; a.eps = c.rms_eps;
     FY_TRY(gemv_bf16w(a, st));
     hipLaunchKernelGGL(sample_k, dim3(B), dim3(256), 0, st, l->logits, NS, c.speech_tokens, l->st, l->max_batch, out_ids, out_ld,
                        l->speech_emb, l->h, H, l->logp_keep, keep_step < FY_LLM_KEEP_LOGP ? keep_step : -1);
@@ -368,13 +388,13 @@ extern "C" int fy_llm_generate(fy_llm* l, const int32_t* text_ids, const int32_t
     l->B = B;
     // prefill
     hipLaunchKernelGGL(embed_rows_k, dim3(R), dim3(256), 0, st, l->row_src, l->embed_tokens, l->speech_emb, l->h, H);
-    FY_TRY(llm_layers(l, R, l->row_seq, l->row_pos, st));
+    FY_TRY(llm_layers(l, R, l->row_seq, l->row_pos, false, st));
     hipLaunchKernelGGL(gather_rows_k, dim3(B), dim3(256), 0, st, l->h, l->last_row, l->hb, H);
     FY_TRY(llm_head_and_sample(l, B, l->hb, out_ids, out_ld, 0, st));
     // decode: row b = sequence b at position st[pos][b]; everything a step needs is on the device
     std::vector<int> done(mb);
     for (int step = 1; step < steps; ++step) {
-        FY_TRY(llm_layers(l, B, l->seq_ids, l->st, st));
+        FY_TRY(llm_layers(l, B, l->seq_ids, l->st, true, st));
         FY_TRY(llm_head_and_sample(l, B, l->h, out_ids, out_ld, step, st));
         if ((step & 7) == 7) {
             HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
