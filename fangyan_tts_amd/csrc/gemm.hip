@@ -6,8 +6,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
 #define GM_BM 128
 #define GM_BN 128
-#define GM_BK 32
-#define GM_PITCH 40          // bf16 elements per LDS row: 32 + 8 pad (80 B, keeps 16-B alignment)
+#define GM_BK 64
+#define GM_PITCH 72          // bf16 elements per LDS row: 64 + 8 pad (144 B: 16-B aligned, spreads ds_read_b128 over banks)
 
 __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& hi, uint4& lo) {
     const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -22,21 +22,31 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
-template <bool PRECISE>
+// C[M,N] = A[M,K] W[N,K]^T.  128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 accumulators of
+// v_mfma_f32_32x32x16_bf16; BK = 64 with two LDS buffers: the global loads of tile t+1 are issued before
+// the 16 MFMAs of tile t and land in the other buffer after them - one barrier per K step.
+// EPI: 0 store bf16, 1 store bf16 after GELU(tanh), 2 store fp32, 3 gated residual (resid += gate * (acc + bias))
+template <bool PRECISE, int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_k(const void* __restrict__ Av, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
-    __shared__ __attribute__((aligned(16))) bf16_t As[(PRECISE ? 2 : 1) * GM_BM * GM_PITCH];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[GM_BN * GM_PITCH];
+    extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
+    constexpr int A_ELEMS = (PRECISE ? 2 : 1) * GM_BM * GM_PITCH, B_ELEMS = GM_BN * GM_PITCH, BUF = A_ELEMS + B_ELEMS;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1, lr = lane & 31, kh = lane >> 5;
-    const int m0 = blockIdx.y * GM_BM, n0 = blockIdx.x * GM_BN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so
+    // workgroup `orig` is given logical tile xcd*chunk + orig/8: every XCD walks a contiguous run of tiles,
+    // N-tiles fastest, and the A rows it is working on are fetched into its L2 once instead of by all eight.
+    const int ntn = (N + GM_BN - 1) / GM_BN, nwg = gridDim.x;
+    const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int m0 = (wg / ntn) * GM_BM, n0 = (wg % ntn) * GM_BN;
     const bf16_t* Ab = (const bf16_t*)Av;
     const float* Af = (const float*)Av;
 
-    uint4 ra[2], ral[2], rb[2];
+    uint4 ra[4], ral[4], rb[4];
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int idx = tid + i * 256, row = idx >> 2, kc = (idx & 3) * 8;
+        for (int i = 0; i < 4; ++i) {
+            int idx = tid + i * 256, row = idx >> 3, kc = (idx & 7) * 8;
             int gm = m0 + row, gn = n0 + row;
             if (PRECISE) {
                 float4 x0 = make_float4(0, 0, 0, 0), x1 = x0;
@@ -52,13 +62,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_k(const void* __restrict__ Av, 
             rb[i] = gn < N ? *reinterpret_cast<const uint4*>(W + (long)gn * K + k0 + kc) : make_uint4(0, 0, 0, 0);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](bf16_t* buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int idx = tid + i * 256, row = idx >> 2, kc = (idx & 3) * 8;
-            *reinterpret_cast<uint4*>(As + row * GM_PITCH + kc) = ra[i];
-            if (PRECISE) *reinterpret_cast<uint4*>(As + GM_BM * GM_PITCH + row * GM_PITCH + kc) = ral[i];
-            *reinterpret_cast<uint4*>(Bs + row * GM_PITCH + kc) = rb[i];
+        for (int i = 0; i < 4; ++i) {
+            int idx = tid + i * 256, row = idx >> 3, kc = (idx & 7) * 8;
+            *reinterpret_cast<uint4*>(buf + row * GM_PITCH + kc) = ra[i];
+            if (PRECISE) *reinterpret_cast<uint4*>(buf + GM_BM * GM_PITCH + row * GM_PITCH + kc) = ral[i];
+            *reinterpret_cast<uint4*>(buf + A_ELEMS + row * GM_PITCH + kc) = rb[i];
         }
     };
 
@@ -71,13 +81,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_k(const void* __restrict__ Av, 
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     load_tile(0);
-    store_tile();
+    store_tile(gm_smem);
     __syncthreads();
-    for (int k0 = 0; k0 < K; k0 += GM_BK) {
-        const bool more = k0 + GM_BK < K;
-        if (more) load_tile(k0 + GM_BK);
+    const int nt = K / GM_BK;
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) load_tile((t + 1) * GM_BK);
+        const bf16_t* As = gm_smem + (t & 1) * BUF;
+        const bf16_t* Bs = As + A_ELEMS;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < GM_BK / 16; ++ks) {
             frag_ab a[2], al[2], b[2];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
@@ -96,39 +109,74 @@ __global__ __launch_bounds__(256) void gemm_bf16_k(const void* __restrict__ Av, 
                     if (PRECISE) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], b[ni], acc[mi][ni], 0, 0, 0);
                 }
         }
+        if (more) store_tile(gm_smem + ((t + 1) & 1) * BUF);
         __syncthreads();
-        if (more) {
-            store_tile();
-            __syncthreads();
-        }
     }
 
+    // epilogue: lane (lr, kh) holds, per accumulator, column n = .. + lr and rows (r&3) + 8(r>>2) + 4kh: a wave's
+    // store instruction covers 2 rows x 32 consecutive columns.  The kind is a template parameter so the 64
+    // element updates are straight-line code; the residual's 64 loads are all in flight before the first use.
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int n = n0 + wn * 64 + ni * 32 + lr;
-        if (n >= N) continue;
-        const float bv = e.bias ? e.bias[n] : 0.f;
-        const float gv = e.mode == EPI_GATE_RESID ? e.gate[n] : 0.f;
+        const bool nok = n < N;
+        const float bv = (e.bias && nok) ? e.bias[n] : 0.f;
+        const float gv = (EPI == 3 && nok) ? e.gate[n] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
+            const int mbase = m0 + wm * 64 + mi * 32 + 4 * kh;
+            if (EPI == 3) {
+                float old[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (m >= M) continue;
-                float v = acc[mi][ni][r] + bv;
-                if (e.mode == EPI_GATE_RESID) {
-                    float* p = e.resid + (long)m * e.ldc + n;
-                    *p = *p + gv * v;
-                } else {
-                    if (e.act == ACT_GELU_TANH) v = act_gelu_tanh(v);
-                    else if (e.act == ACT_SILU) v = act_silu(v);
-                    else if (e.act == ACT_MISH) v = act_mish(v);
-                    if (e.out_bf16) ((bf16_t*)e.out)[(long)m * e.ldc + n] = f32_to_bf16(v);
-                    else ((float*)e.out)[(long)m * e.ldc + n] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    old[r] = (nok && m < M) ? e.resid[(long)m * e.ldc + n] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (nok && m < M) e.resid[(long)m * e.ldc + n] = old[r] + gv * (acc[mi][ni][r] + bv);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    float v = acc[mi][ni][r] + bv;
+                    if (EPI == 1) v = act_gelu_tanh(v);
+                    if (nok && m < M) {
+                        if (EPI == 2) ((float*)e.out)[(long)m * e.ldc + n] = v;
+                        else ((bf16_t*)e.out)[(long)m * e.ldc + n] = f32_to_bf16(v);
+                    }
                 }
             }
         }
     }
+}
+
+template <bool PRECISE, int EPI>
+static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)2 * ((PRECISE ? 2 : 1) * GM_BM + GM_BN) * GM_PITCH * sizeof(bf16_t);
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_k<PRECISE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid(cdiv(N, GM_BN) * cdiv(M, GM_BM));
+    hipLaunchKernelGGL((gemm_bf16_k<PRECISE, EPI>), grid, dim3(256), lds, st, A, lda, W, M, N, K, epi);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+template <bool PRECISE>
+static int gemm_launch(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
+    if (epi.mode == EPI_GATE_RESID) return gemm_launch2<PRECISE, 3>(A, lda, W, M, N, K, epi, st);
+    if (!epi.out_bf16) {
+        FY_CHECK(epi.act == ACT_NONE, FY_ERR_ARG, "gemm: fp32 output has no fused activation");
+        return gemm_launch2<PRECISE, 2>(A, lda, W, M, N, K, epi, st);
+    }
+    if (epi.act == ACT_GELU_TANH) return gemm_launch2<PRECISE, 1>(A, lda, W, M, N, K, epi, st);
+    FY_CHECK(epi.act == ACT_NONE, FY_ERR_ARG, "gemm: only GELU(tanh) is fused");
+    return gemm_launch2<PRECISE, 0>(A, lda, W, M, N, K, epi, st);
 }
 
 static int gemm_check(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& e, int a_elem) {
@@ -140,19 +188,13 @@ static int gemm_check(const void* A, int lda, const bf16_t* W, int M, int N, int
 
 int gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     FY_TRY(gemm_check(A, lda, W, M, N, K, epi, 2));
-    dim3 grid(cdiv(N, GM_BN), cdiv(M, GM_BM));
     ProfScope prof("gemm_bf16", 2.0 * M * N * K, st);
-    hipLaunchKernelGGL(gemm_bf16_k<false>, grid, dim3(256), 0, st, (const void*)A, lda, W, M, N, K, epi);
-    HIP_TRY(hipGetLastError());
-    return FY_OK;
+    return gemm_launch<false>(A, lda, W, M, N, K, epi, st);
 }
 
 int gemm_f32a_precise(const float* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     FY_TRY(gemm_check(A, lda, W, M, N, K, epi, 4));
-    dim3 grid(cdiv(N, GM_BN), cdiv(M, GM_BM));
-    hipLaunchKernelGGL(gemm_bf16_k<true>, grid, dim3(256), 0, st, (const void*)A, lda, W, M, N, K, epi);
-    HIP_TRY(hipGetLastError());
-    return FY_OK;
+    return gemm_launch<true>(A, lda, W, M, N, K, epi, st);
 }
 
 __global__ void cast_f32_bf16_k(const float* __restrict__ s, bf16_t* __restrict__ d, size_t n) {
