@@ -19,6 +19,10 @@ __device__ __forceinline__ float apply_pre(float v, int act, float slope, float 
     if (act == ACT_SNAKE) return act_snake(v, alpha);
     return v;
 }
+__device__ __forceinline__ float snake_fast(float x, float a) {
+    float s = __sinf(x * a);
+    return fmaf(__builtin_amdgcn_rcpf(a + 1e-9f), s * s, x);
+}
 __device__ __forceinline__ float apply_post(float v, int act, float slope) {
     if (act == ACT_ELU) return act_elu(v);
     if (act == ACT_LEAKY) return act_leaky(v, slope);
@@ -209,8 +213,14 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
                     v.z = act_leaky(v.z, d.pre_slope); v.w = act_leaky(v.w, d.pre_slope);
                 } else if (d.pre_act == ACT_SNAKE) {
                     float4 a = *reinterpret_cast<const float4*>(d.alpha + ci_base + ci);
-                    v.x = act_snake(v.x, a.x); v.y = act_snake(v.y, a.y);
-                    v.z = act_snake(v.z, a.z); v.w = act_snake(v.w, a.w);
+                    if (PRECISE) {
+                        v.x = act_snake(v.x, a.x); v.y = act_snake(v.y, a.y);
+                        v.z = act_snake(v.z, a.z); v.w = act_snake(v.w, a.w);
+                    } else {
+                        // the operand is rounded to bf16 next: hardware sine / reciprocal (~1e-6) are ample
+                        v.x = snake_fast(v.x, a.x); v.y = snake_fast(v.y, a.y);
+                        v.z = snake_fast(v.z, a.z); v.w = snake_fast(v.w, a.w);
+                    }
                 }
             }
             bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
@@ -228,35 +238,62 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
         }
         __syncthreads();
         if (!wave_live) continue;
-        const int c16_0 = ci0 / 16;
-        for (int t = 0; t < d.KW; ++t) {
+        const int c16_0 = ci0 / 16, nk = ccn / 16;           // nk <= MF_CC/16 = 8
+        // weights of one tap (all k-steps of this channel chunk, two 32-column tiles) are requested as one batch,
+        // one tap ahead of the MFMAs that use them: L2 latency is paid once per tap, under the previous tap's math
+        auto load_b = [&](int t, frag_ab (&bb)[MF_CC / 16][2]) {
+            const bf16_t* wt = wp + ((((long)g * d.KW + t) * C16 + c16_0) * N32 + n32_base) * 512 + lane * 8;
+#pragma unroll
+            for (int kk = 0; kk < MF_CC / 16; ++kk) {
+                if (kk < nk) {
+                    bb[kk][0] = *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512);
+                    bb[kk][1] = tile1_live ? *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512 + 512) : bb[kk][0];
+                }
+            }
+        };
+        auto tap = [&](int t, const frag_ab (&bb)[MF_CC / 16][2]) {
             int arow[2];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 int s = p0 + wpi * 64 + mi * 32 + lr + t * d.dil - d.pad_left;
                 arow[mi] = ((d.up == 1) ? s : floordiv(s, d.up)) - row_lo;
             }
-            const bf16_t* wt = wp + ((((long)g * d.KW + t) * C16 + c16_0) * N32 + n32_base) * 512 + lane * 8;
-            for (int kk = 0; kk < ccn / 16; ++kk) {
-                frag_ab bfr[2];
-                bfr[0] = *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512);
-                bfr[1] = tile1_live ? *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512 + 512) : bfr[0];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) {
-                    size_t off = (size_t)arow[mi] * MF_ROWB + (kk * 16 + kh * 8) * 2;
-                    frag_ab a = *reinterpret_cast<const frag_ab*>(smem + off);
-                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[0], acc[mi][0], 0, 0, 0);
-                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bfr[1], acc[mi][1], 0, 0, 0);
-                    if (PRECISE) {
-                        frag_ab al = *reinterpret_cast<const frag_ab*>(lo_tile + off);
-                        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr[0], acc[mi][0], 0, 0, 0);
-                        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bfr[1], acc[mi][1], 0, 0, 0);
+            for (int kk = 0; kk < MF_CC / 16; ++kk) {
+                if (kk < nk) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        size_t off = (size_t)arow[mi] * MF_ROWB + (kk * 16 + kh * 8) * 2;
+                        frag_ab a = *reinterpret_cast<const frag_ab*>(smem + off);
+                        acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb[kk][0], acc[mi][0], 0, 0, 0);
+                        acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb[kk][1], acc[mi][1], 0, 0, 0);
+                        if (PRECISE) {
+                            frag_ab al = *reinterpret_cast<const frag_ab*>(lo_tile + off);
+                            acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bb[kk][0], acc[mi][0], 0, 0, 0);
+                            acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bb[kk][1], acc[mi][1], 0, 0, 0);
+                        }
                     }
                 }
+            }
+        };
+        frag_ab b0[MF_CC / 16][2], b1[MF_CC / 16][2];
+        load_b(0, b0);
+        for (int t = 0; t < d.KW; t += 2) {
+            if (t + 1 < d.KW) load_b(t + 1, b1);
+            tap(t, b0);
+            if (t + 1 < d.KW) {
+                if (t + 2 < d.KW) load_b(t + 2, b0);
+                tap(t + 1, b1);
             }
         }
     }
     if (!wave_live) return;
+    // epilogue: flags are wave-uniform, so each variant is straight-line code; the residual / accumulate
+    // operands of a 16-row fragment are all requested before the first store
+    const float osc = d.out_scale;
+    const int qoff = d.reflect1 ? 1 : 0;
+    float* yb = d.y + (long)b * d.y_bs;
+    const float* rb = d.add_resid ? d.resid + (long)b * d.r_bs : nullptr;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         if (ni == 1 && !tile1_live) break;
@@ -264,10 +301,27 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
         const float bv = d.bias ? d.bias[co] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
+            const int pbase = p0 + wpi * 64 + mi * 32 + 4 * kh;
+            float rv[16], ov[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int p = p0 + wpi * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (p < n_out) conv_store(d, b, p, co, acc[mi][ni][r] + bv);
+                const int p = pbase + (r & 3) + 8 * (r >> 2);
+                const long q = p + qoff;
+                rv[r] = (rb && p < n_out) ? rb[q * d.r_ld + co] : 0.f;
+                ov[r] = (d.accumulate && p < n_out) ? yb[q * d.y_ld + co] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = pbase + (r & 3) + 8 * (r >> 2);
+                if (p >= n_out) continue;
+                float v = apply_post(acc[mi][ni][r] + bv, d.post_act, d.post_slope);
+                const long q = p + qoff;
+                yb[q * d.y_ld + co] = ov[r] + (v + rv[r]) * osc;
+                if (d.reflect1 && p == 1) {                  // ReflectionPad1d((1,0)): row 0 mirrors conv row 1
+                    float r0 = rb ? rb[co] : 0.f;
+                    float o0 = d.accumulate ? yb[co] : 0.f;
+                    yb[co] = o0 + (v + r0) * osc;
+                }
             }
         }
     }
