@@ -75,6 +75,13 @@ __device__ inline float act_elu(float x) { return x > 0.f ? x : expm1f(x); }
 __device__ inline float act_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ inline float act_mish(float x) { return x * tanhf(act_softplus(x)); }
 __device__ inline float act_silu(float x) { return x / (1.0f + expf(-x)); }
+// tanh-GELU on values that are rounded to bf16 next: tanh(u) = 1 - 2 / (exp(2u) + 1) with the hardware exp
+__device__ inline float act_gelu_tanh_fast(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    float t = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f);
+    return 0.5f * x * (1.0f + t);
+}
 __device__ inline float act_gelu_tanh(float x) {
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;
     return 0.5f * x * (1.0f + tanhf(k0 * (x + k1 * x * x * x)));

@@ -5,6 +5,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
 #define GM_BM 128
+int gemm_tile_override = 0;        // 0 auto, 128 or 256: forces the M tile (microbenchmarks)
 #define GM_BN 128
 #define GM_BK 64
 #define GM_PITCH 72          // bf16 elements per LDS row: 64 + 8 pad (144 B: 16-B aligned, spreads ds_read_b128 over banks)
@@ -26,10 +27,12 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
 // v_mfma_f32_32x32x16_bf16; BK = 64 with two LDS buffers: the global loads of tile t+1 are issued before
 // the 16 MFMAs of tile t and land in the other buffer after them - one barrier per K step.
 // EPI: 0 store bf16, 1 store bf16 after GELU(tanh), 2 store fp32, 3 gated residual (resid += gate * (acc + bias))
-template <bool PRECISE, int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_k(const void* __restrict__ Av, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
+template <bool PRECISE, int EPI, int BM>
+__global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ Av, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
     extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
-    constexpr int A_ELEMS = (PRECISE ? 2 : 1) * GM_BM * GM_PITCH, B_ELEMS = GM_BN * GM_PITCH, BUF = A_ELEMS + B_ELEMS;
+    constexpr int NT = BM * 2;                               // threads: (BM/64) x 2 waves, each a 64x64 tile
+    constexpr int A_ELEMS = (PRECISE ? 2 : 1) * BM * GM_PITCH, B_ELEMS = GM_BN * GM_PITCH, BUF = A_ELEMS + B_ELEMS;
+    constexpr int A_LOADS = BM * 8 / NT, B_LOADS = GM_BN * 8 / NT;      // 16-B chunks per thread per tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1, lr = lane & 31, kh = lane >> 5;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (each with its own 4 MiB L2), so
@@ -38,16 +41,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_k(const void* __restrict__ Av, 
     const int ntn = (N + GM_BN - 1) / GM_BN, nwg = gridDim.x;
     const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int m0 = (wg / ntn) * GM_BM, n0 = (wg % ntn) * GM_BN;
+    const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * GM_BN;
     const bf16_t* Ab = (const bf16_t*)Av;
     const float* Af = (const float*)Av;
 
-    uint4 ra[4], ral[4], rb[4];
+    uint4 ra[A_LOADS], ral[A_LOADS], rb[B_LOADS];
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int idx = tid + i * 256, row = idx >> 3, kc = (idx & 7) * 8;
-            int gm = m0 + row, gn = n0 + row;
+        for (int i = 0; i < A_LOADS; ++i) {
+            int idx = tid + i * NT, row = idx >> 3, kc = (idx & 7) * 8;
+            int gm = m0 + row;
             if (PRECISE) {
                 float4 x0 = make_float4(0, 0, 0, 0), x1 = x0;
                 if (gm < M) {
@@ -59,15 +62,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_k(const void* __restrict__ Av, 
             } else {
                 ra[i] = gm < M ? *reinterpret_cast<const uint4*>(Ab + (long)gm * lda + k0 + kc) : make_uint4(0, 0, 0, 0);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            int idx = tid + i * NT, row = idx >> 3, kc = (idx & 7) * 8;
+            int gn = n0 + row;
             rb[i] = gn < N ? *reinterpret_cast<const uint4*>(W + (long)gn * K + k0 + kc) : make_uint4(0, 0, 0, 0);
         }
     };
     auto store_tile = [&](bf16_t* buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int idx = tid + i * 256, row = idx >> 3, kc = (idx & 7) * 8;
+        for (int i = 0; i < A_LOADS; ++i) {
+            int idx = tid + i * NT, row = idx >> 3, kc = (idx & 7) * 8;
             *reinterpret_cast<uint4*>(buf + row * GM_PITCH + kc) = ra[i];
-            if (PRECISE) *reinterpret_cast<uint4*>(buf + GM_BM * GM_PITCH + row * GM_PITCH + kc) = ral[i];
+            if (PRECISE) *reinterpret_cast<uint4*>(buf + BM * GM_PITCH + row * GM_PITCH + kc) = ral[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            int idx = tid + i * NT, row = idx >> 3, kc = (idx & 7) * 8;
             *reinterpret_cast<uint4*>(buf + A_ELEMS + row * GM_PITCH + kc) = rb[i];
         }
     };
@@ -96,7 +108,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_k(const void* __restrict__ Av, 
             for (int mi = 0; mi < 2; ++mi) {
                 int off = (wm * 64 + mi * 32 + lr) * GM_PITCH + ks * 16 + kh * 8;
                 a[mi] = *reinterpret_cast<const frag_ab*>(As + off);
-                if (PRECISE) al[mi] = *reinterpret_cast<const frag_ab*>(As + GM_BM * GM_PITCH + off);
+                if (PRECISE) al[mi] = *reinterpret_cast<const frag_ab*>(As + BM * GM_PITCH + off);
             }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
@@ -113,58 +125,75 @@ __global__ __launch_bounds__(256) void gemm_bf16_k(const void* __restrict__ Av, 
         __syncthreads();
     }
 
-    // epilogue: lane (lr, kh) holds, per accumulator, column n = .. + lr and rows (r&3) + 8(r>>2) + 4kh: a wave's
-    // store instruction covers 2 rows x 32 consecutive columns.  The kind is a template parameter so the 64
-    // element updates are straight-line code; the residual's 64 loads are all in flight before the first use.
+    // epilogue through LDS: the accumulator layout (column on the lane, rows in registers) would store 2-4 bytes
+    // per lane; each wave instead parks its 64x64 tile in LDS (the operand buffers are free now) and reads it
+    // back row-wise, so every lane moves 4 consecutive columns: 16 wide stores per lane instead of 64 narrow ones.
+    constexpr int EP = 68;                                   // fp32 pitch of the per-wave tile
+    float* et = reinterpret_cast<float*>(gm_smem) + wid * 64 * EP;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = n0 + wn * 64 + ni * 32 + lr;
-        const bool nok = n < N;
-        const float bv = (e.bias && nok) ? e.bias[n] : 0.f;
-        const float gv = (EPI == 3 && nok) ? e.gate[n] : 0.f;
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int mbase = m0 + wm * 64 + mi * 32 + 4 * kh;
-            if (EPI == 3) {
-                float old[16];
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    old[r] = (nok && m < M) ? e.resid[(long)m * e.ldc + n] : 0.f;
-                }
+            for (int r = 0; r < 16; ++r) et[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * EP + ni * 32 + lr] = acc[mi][ni][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the wave reads back only its own tile
+    __builtin_amdgcn_wave_barrier();
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int n = n0 + wn * 64 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gv = bv;
+    if (n < N) {                                             // N % 4 == 0 is checked on the host
+        if (e.bias) bv = *reinterpret_cast<const float4*>(e.bias + n);
+        if (EPI == 3) gv = *reinterpret_cast<const float4*>(e.gate + n);
+    }
+    float4 old[16];
+    if (EPI == 3) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    if (nok && m < M) e.resid[(long)m * e.ldc + n] = old[r] + gv * (acc[mi][ni][r] + bv);
-                }
-            } else {
+        for (int it = 0; it < 16; ++it) {
+            const int m = m0 + wm * 64 + it * 4 + rsub;
+            old[it] = (n < N && m < M) ? *reinterpret_cast<const float4*>(e.resid + (long)m * e.ldc + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = mbase + (r & 3) + 8 * (r >> 2);
-                    float v = acc[mi][ni][r] + bv;
-                    if (EPI == 1) v = act_gelu_tanh(v);
-                    if (nok && m < M) {
-                        if (EPI == 2) ((float*)e.out)[(long)m * e.ldc + n] = v;
-                        else ((bf16_t*)e.out)[(long)m * e.ldc + n] = f32_to_bf16(v);
-                    }
-                }
-            }
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + rsub, m = m0 + wm * 64 + row;
+        float4 v = *reinterpret_cast<const float4*>(et + row * EP + c4);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (n >= N || m >= M) continue;
+        if (EPI == 3) {
+            float4 o = old[it];
+            o.x = fmaf(gv.x, v.x, o.x); o.y = fmaf(gv.y, v.y, o.y); o.z = fmaf(gv.z, v.z, o.z); o.w = fmaf(gv.w, v.w, o.w);
+            *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + n) = o;
+        } else if (EPI == 2) {
+            *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
+        } else {
+            if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+            *reinterpret_cast<uint2*>((bf16_t*)e.out + (long)m * e.ldc + n) = pk;
         }
     }
 }
 
-template <bool PRECISE, int EPI>
-static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
+template <bool PRECISE, int EPI, int BM>
+static int gemm_launch3(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = (size_t)2 * ((PRECISE ? 2 : 1) * GM_BM + GM_BN) * GM_PITCH * sizeof(bf16_t);
+    const size_t lds = (size_t)2 * ((PRECISE ? 2 : 1) * BM + GM_BN) * GM_PITCH * sizeof(bf16_t);
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_k<PRECISE, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_k<PRECISE, EPI, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid(cdiv(N, GM_BN) * cdiv(M, GM_BM));
-    hipLaunchKernelGGL((gemm_bf16_k<PRECISE, EPI>), grid, dim3(256), lds, st, A, lda, W, M, N, K, epi);
+    dim3 grid(cdiv(N, GM_BN) * cdiv(M, BM));
+    hipLaunchKernelGGL((gemm_bf16_k<PRECISE, EPI, BM>), grid, dim3(BM * 2), lds, st, A, lda, W, M, N, K, epi);
     HIP_TRY(hipGetLastError());
     return FY_OK;
+}
+
+// 256x128 tiles move 25 % fewer operand bytes per flop through L2 (the binding resource at these shapes); they
+// are used when they still fill the chip (>= 1 workgroup per CU) and the split operand of the precise form is off
+template <bool PRECISE, int EPI>
+static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
+    return gemm_launch3<PRECISE, EPI, 128>(A, lda, W, M, N, K, epi, st);
 }
 
 template <bool PRECISE>
@@ -183,6 +212,7 @@ static int gemm_check(const void* A, int lda, const bf16_t* W, int M, int N, int
     FY_CHECK(A && W && M >= 1 && N >= 1 && K >= GM_BK && K % GM_BK == 0, FY_ERR_ARG, "gemm: bad shape M %d N %d K %d", M, N, K);
     FY_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && (lda * a_elem) % 16 == 0, FY_ERR_ARG, "gemm: operands must be 16-B aligned");
     FY_CHECK(e.ldc >= N && ((e.mode == EPI_STORE && e.out) || (e.mode == EPI_GATE_RESID && e.resid && e.gate)), FY_ERR_ARG, "gemm: bad epilogue");
+    FY_CHECK(N % 4 == 0 && e.ldc % 4 == 0, FY_ERR_ARG, "gemm: N and the output pitch must be multiples of 4 (N %d, ldc %d)", N, e.ldc);
     return FY_OK;
 }
 
