@@ -153,8 +153,14 @@ def main():
     L.fy_prof_reset()
     ms, flops, n = prof["gemm_bf16"]
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    roofline = {"bound": "mfma", "kernel": "gemm_bf16_k<false> (DiT linears, 128x128x32 tile)", "achieved": round(achieved, 2),
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+    # HBM-side traffic per launch of the same kernel on the same shapes: PMC counters cannot be read from
+    # inside this process, so the figure is the one rocprofv3 measured (profiles/r01_gemm_pmc.json says how)
+    traffic, pmc = None, os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
+    if os.path.exists(pmc):
+        traffic = json.load(open(pmc)).get("dit_mix_traffic_bytes_per_launch")
+    roofline = {"bound": "mfma", "kernel": "gemm_bf16_k (DiT linears, 128x128x64 tile)", "achieved": round(achieved, 2),
+                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_gemm_pmc.json)",
                 "launches_per_step": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                 "gflop_per_launch": round(flops / max(n, 1) / 1e9, 3),
                 "stage_ms_per_step": {k: round(v[0], 3) for k, v in prof.items()}}
