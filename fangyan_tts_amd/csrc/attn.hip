@@ -45,23 +45,34 @@ __global__ __launch_bounds__(256) void dit_attention_k(const bf16_t* __restrict_
     int kend = len;
     if (chunk > 0) kend = min(len, ((min(q0 + 63, len - 1) / chunk) + 1) * chunk);
     bf16_t* pw = Pw + wid * 16 * AT_PITCH;
+    // K/V tiles are fetched one tile ahead into registers: the loads of tile t+1 fly under the MFMAs of tile t
+    uint4 kreg[2], vreg[2];
+    auto load_kv = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int idx = tid + i * 256, key = idx >> 3, dc = (idx & 7) * 8;
+            kreg[i] = make_uint4(0, 0, 0, 0);
+            vreg[i] = kreg[i];
+            if (k0 + key < len) {
+                const bf16_t* p = base + (long)(k0 + key) * ld + h * AT_D + dc;
+                kreg[i] = *reinterpret_cast<const uint4*>(p + H * AT_D);
+                vreg[i] = *reinterpret_cast<const uint4*>(p + 2 * H * AT_D);
+            }
+        }
+    };
+    load_kv(0);
     for (int k0 = 0; k0 < kend; k0 += 64) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int idx = tid + i * 256, key = idx >> 3, dc = (idx & 7) * 8;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = kv;
-            if (k0 + key < len) {
-                const bf16_t* p = base + (long)(k0 + key) * ld + h * AT_D + dc;
-                kv = *reinterpret_cast<const uint4*>(p + H * AT_D);
-                vv = *reinterpret_cast<const uint4*>(p + 2 * H * AT_D);
-            }
-            *reinterpret_cast<uint4*>(Ks + key * AT_PITCH + dc) = kv;
-            const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
+            *reinterpret_cast<uint4*>(Ks + key * AT_PITCH + dc) = kreg[i];
+            const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vreg[i]);
 #pragma unroll
             for (int j = 0; j < 8; ++j) Vt[(dc + j) * AT_PITCH + key] = ve[j];
         }
         __syncthreads();
+        if (k0 + 64 < kend) load_kv(k0 + 64);
         // S = Q K^T for this wave's 16 rows x 64 keys: sc[nb][r] = S[row 4g+r][key 16nb+lc]
         f32x4 sc[4];
 #pragma unroll
