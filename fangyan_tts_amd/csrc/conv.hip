@@ -201,26 +201,32 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
         const int ccn = min(MF_CC, Cin_gp - ci0);          // multiple of 16
         const int q4 = ccn / 4;
         __syncthreads();
-        for (int idx = tid; idx < nrows * q4; idx += NT) {
-            int r = idx / q4, c4 = (idx % q4) * 4;
-            int row = row_lo + r;
-            int ci = ci0 + c4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row >= 0 && row < n_in && ci < Cin_g) {
-                v = *reinterpret_cast<const float4*>(xb + (long)row * d.x_ld + ci_base + ci);
-                if (d.pre_act == ACT_LEAKY) {
-                    v.x = act_leaky(v.x, d.pre_slope); v.y = act_leaky(v.y, d.pre_slope);
-                    v.z = act_leaky(v.z, d.pre_slope); v.w = act_leaky(v.w, d.pre_slope);
-                } else if (d.pre_act == ACT_SNAKE) {
-                    float4 a = *reinterpret_cast<const float4*>(d.alpha + ci_base + ci);
-                    if (PRECISE) {
-                        v.x = act_snake(v.x, a.x); v.y = act_snake(v.y, a.y);
-                        v.z = act_snake(v.z, a.z); v.w = act_snake(v.w, a.w);
-                    } else {
-                        // the operand is rounded to bf16 next: hardware sine / reciprocal (~1e-6) are ample
-                        v.x = snake_fast(v.x, a.x); v.y = snake_fast(v.y, a.y);
-                        v.z = snake_fast(v.z, a.z); v.w = snake_fast(v.w, a.w);
-                    }
+        // branch-free and unrolled: out-of-range rows / channels read a clamped address and are zeroed by a select,
+        // so the compiler keeps several of a thread's loads in flight instead of one wait per item
+        const int total = nrows * q4;
+        const bool q4_pow2 = (q4 & (q4 - 1)) == 0;
+        const int q4_sh = 31 - __clz(q4);
+        const int row_max = max(n_in - 1, 0), ci_max = max(Cin_g - 4, 0);
+#pragma unroll 4
+        for (int idx = tid; idx < total; idx += NT) {
+            const int r = q4_pow2 ? (idx >> q4_sh) : idx / q4;
+            const int c4 = (idx - r * q4) * 4;
+            const int row = row_lo + r, ci = ci0 + c4;
+            const bool ok = row >= 0 && row < n_in && ci < Cin_g;
+            float4 v = *reinterpret_cast<const float4*>(xb + (long)min(max(row, 0), row_max) * d.x_ld + ci_base + min(ci, ci_max));
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.pre_act == ACT_LEAKY) {
+                v.x = act_leaky(v.x, d.pre_slope); v.y = act_leaky(v.y, d.pre_slope);
+                v.z = act_leaky(v.z, d.pre_slope); v.w = act_leaky(v.w, d.pre_slope);
+            } else if (d.pre_act == ACT_SNAKE) {
+                float4 a = *reinterpret_cast<const float4*>(d.alpha + ci_base + min(ci, ci_max));
+                if (PRECISE) {
+                    v.x = act_snake(v.x, a.x); v.y = act_snake(v.y, a.y);
+                    v.z = act_snake(v.z, a.z); v.w = act_snake(v.w, a.w);
+                } else {
+                    // the operand is rounded to bf16 next: hardware sine / reciprocal (~1e-6) are ample
+                    v.x = snake_fast(v.x, a.x); v.y = snake_fast(v.y, a.y);
+                    v.z = snake_fast(v.z, a.z); v.w = snake_fast(v.w, a.w);
                 }
             }
             bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
