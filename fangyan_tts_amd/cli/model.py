@@ -23,7 +23,7 @@ class CosyVoice3Model:
                  hift_weights: Dict[str, torch.Tensor], cfg: ModelCfg = ModelCfg(), device: Optional[torch.device] = None,
                  max_batch: int = 8, max_text: int = 128, max_prompt_tokens: int = 800, max_tokens: int = 800,
                  rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
-                 sine_noise: Optional[torch.Tensor] = None, fp16: bool = False):
+                 sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -31,7 +31,7 @@ class CosyVoice3Model:
         self.max_batch, self.max_tokens, self.max_prompt_tokens = max_batch, max_tokens, max_prompt_tokens
         max_frames = 2 * (max_tokens + max_prompt_tokens)
         self.llm = LlmEngine(llm_weights, cfg.llm, max_batch=max_batch, max_ctx=2 + max_text + max_prompt_tokens + max_tokens,
-                             device=self.device)
+                             device=self.device, keep_weights=keep_llm_weights)
         self.flow = FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device)
         self.hift = HiftEngine(hift_weights, cfg.hift, max_batch=max_batch, max_frames=2 * max_tokens, device=self.device)
         # The reference draws these buffers once at construction and never stores them in a checkpoint

@@ -25,17 +25,40 @@ class LlmEngine:
     """weights: the llm.pt state_dict (reference key names, fp32 CUDA tensors; lm_head not needed)."""
 
     def __init__(self, weights: Dict[str, torch.Tensor], cfg: LlmCfg = LlmCfg(), max_batch: int = 8, max_ctx: int = 1024,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, keep_weights: bool = False):
         self.cfg = cfg
         self.device = device or next(iter(weights.values())).device
         self.max_batch, self.max_ctx = max_batch, max_ctx
         self._h = C.c_void_p()
         weights = {k: v for k, v in weights.items() if "lm_head" not in k}
+        self._weights = weights if keep_weights else None          # needed only for load_state_dict
+        self._create(weights)
+
+    def _create(self, weights):
         arr, keep = _lib.tensor_table(weights)
-        cs = _cfg_struct(cfg)
+        cs = _cfg_struct(self.cfg)
         with torch.cuda.device(self.device):
-            check(_lib.lib().fy_llm_create(C.byref(self._h), C.byref(cs), arr, len(weights), max_batch, max_ctx, self._stream()))
+            check(_lib.lib().fy_llm_create(C.byref(self._h), C.byref(cs), arr, len(weights), self.max_batch, self.max_ctx, self._stream()))
         del keep
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        """torch.nn.Module.load_state_dict's contract for the keys of llm.pt (compare_inference.py:36-43 swaps a
+        fine-tuned LM in with strict=False): the engine is rebuilt from the merged weights."""
+        if self._weights is None:
+            raise RuntimeError("LlmEngine was built without keep_weights=True; it cannot merge a partial state_dict")
+        known = set(self._weights) | {"llm.model.lm_head.weight"}
+        unexpected = [k for k in state_dict if k not in known]
+        missing = [k for k in self._weights if k not in state_dict]
+        if strict and (unexpected or missing):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}, unexpected {unexpected[:5]}")
+        for k, v in state_dict.items():
+            if k in self._weights:
+                if tuple(v.shape) != tuple(self._weights[k].shape):
+                    raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(self._weights[k].shape)}")
+                self._weights[k] = v.detach().to(self.device, torch.float32).contiguous()
+        self.close()
+        self._create(self._weights)
+        return missing, unexpected
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

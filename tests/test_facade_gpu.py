@@ -1,0 +1,110 @@
+"""GPU test of the user-facing facade: AutoModel(model_dir) -> inference_instruct2 / zero_shot generators,
+model.model.llm.load_state_dict(..., strict=False), model.sample_rate - the calls compare_inference.py makes
+(compare_inference.py:29-61) - on a synthetic model directory with a stand-in frontend."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fangyan_tts_amd import synth
+from fangyan_tts_amd.spec import ModelCfg
+from gpu_util import maxerr, synth_mel
+
+pytestmark = pytest.mark.gpu
+
+YAML = """
+# scalars only matter; tags are HyperPyYAML's
+sample_rate: 24000
+llm_input_size: 256
+chunk_size: 25
+token_mel_ratio: 2
+flow: !new:cosyvoice.flow.flow.CausalMaskedDiffWithDiT
+    vocab_size: 6561
+    decoder: !new:cosyvoice.flow.flow_matching.CausalConditionalCFM
+        cfm_params: !new:omegaconf.DictConfig
+            content:
+                inference_cfg_rate: 0.7
+hift: !new:cosyvoice.hifigan.generator.CausalHiFTGenerator
+    upsample_rates: [8, 5, 3]
+    nsf_voiced_threshold: 10
+"""
+
+
+class FakeFrontEnd:
+    """Stands in for cli/frontend.py: deterministic ids / features from the strings."""
+
+    def __init__(self, cfg):
+        self.cfg, self.spk2info = cfg, {}
+
+    def text_normalize(self, text, split=True, text_frontend=True):
+        return [text] if split else text
+
+    def _ids(self, text, n):
+        return torch.from_numpy(synth.randint("fe." + text, (1, n), 0, self.cfg.llm.vocab))
+
+    def frontend_zero_shot(self, tts_text, prompt_text, prompt_wav, resample_rate, zero_shot_spk_id):
+        p = 12
+        tok = torch.from_numpy(synth.randint("fe.tok." + prompt_wav, (1, p), 0, 6561))
+        feat = torch.from_numpy(synth_mel("fe.feat." + prompt_wav, 2 * p))
+        emb = torch.from_numpy(synth.normal("fe.spk." + prompt_wav, (1, 192)))
+        return {"text": self._ids(tts_text, 7), "text_len": torch.tensor([7]), "prompt_text": self._ids(prompt_text, 5),
+                "prompt_text_len": torch.tensor([5]), "llm_prompt_speech_token": tok, "llm_prompt_speech_token_len": torch.tensor([p]),
+                "flow_prompt_speech_token": tok, "flow_prompt_speech_token_len": torch.tensor([p]), "prompt_speech_feat": feat,
+                "prompt_speech_feat_len": torch.tensor([2 * p]), "llm_embedding": emb, "flow_embedding": emb}
+
+    def frontend_instruct2(self, tts_text, instruct_text, prompt_wav, resample_rate, zero_shot_spk_id):
+        d = self.frontend_zero_shot(tts_text, instruct_text, prompt_wav, resample_rate, zero_shot_spk_id)
+        del d["llm_prompt_speech_token"], d["llm_prompt_speech_token_len"]
+        return d
+
+
+@pytest.fixture(scope="module")
+def model_dir(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cv3")
+    cfg = ModelCfg.tiny()
+    (d / "cosyvoice3.yaml").write_text(YAML)
+    for name, m in (("llm", cfg.llm), ("flow", cfg.flow), ("hift", cfg.hift)):
+        sd = {k: torch.from_numpy(v) for k, v in synth.state_dict(m.manifest()).items()}
+        if name == "hift":
+            sd = {"generator." + k: v for k, v in sd.items()}             # as saved by the GAN trainer, cli/model.py:71
+        if name == "llm":
+            sd["epoch"] = torch.tensor(3)                                   # train bookkeeping must be ignored
+        torch.save(sd, d / f"{name}.pt")
+    return str(d), cfg
+
+
+def test_automodel_drop_in_calls(model_dir):
+    from cosyvoice.cli.cosyvoice import AutoModel                            # the reference's import path
+    path, cfg = model_dir
+    model = AutoModel(model_dir=path, frontend=FakeFrontEnd(cfg), max_tokens=160, max_prompt_tokens=32)
+    assert model.sample_rate == 24000 and model.cfg == cfg
+    outs = list(model.inference_instruct2("你好世界", "用四川话说<|endofprompt|>", "prompt.wav", stream=False))
+    assert len(outs) == 1
+    wav = outs[0]["tts_speech"]
+    assert wav.dtype == torch.float32 and wav.device.type == "cpu" and wav.dim() == 2 and wav.shape[0] == 1
+    assert wav.shape[1] % 480 == 0 and float(wav.abs().max()) <= 0.99 + 1e-6
+    # same call through the batched engine entry
+    fe = FakeFrontEnd(cfg)
+    w2, s2, _ = model.model.tts_batch([fe.frontend_instruct2("你好世界", "用四川话说<|endofprompt|>", "prompt.wav", 24000, "")])
+    assert maxerr(w2[:, : s2[0]], wav) == 0.0
+    z = list(model.inference_zero_shot("你好世界", "提示<|endofprompt|>", "prompt.wav"))[0]["tts_speech"]
+    assert z.shape[1] % 480 == 0
+    # compare_inference.py:36-43: swap LLM weights, strict=False, extra keys ignored
+    sd = {k: torch.from_numpy(v) for k, v in synth.state_dict(cfg.llm.manifest()).items() if "layers.1." in k}
+    sd = {k: v * 0.5 for k, v in sd.items()}
+    sd["step"] = torch.tensor(1)
+    sd = {k: v for k, v in sd.items() if not k.startswith("epoch") and not k.startswith("step")}
+    model.model.llm.load_state_dict(sd, strict=False)
+    wav3 = list(model.inference_instruct2("你好世界", "用四川话说<|endofprompt|>", "prompt.wav"))[0]["tts_speech"]
+    assert wav3.shape != wav.shape or maxerr(wav3, wav) > 1e-4                # the swapped weights are really in use
+    with pytest.raises(RuntimeError):
+        model.model.llm.load_state_dict(sd, strict=True)
+
+
+def test_automodel_errors(tmp_path):
+    from fangyan_tts_amd.cli.cosyvoice import AutoModel
+    with pytest.raises(ValueError):
+        AutoModel(model_dir=str(tmp_path / "nope"))
+    with pytest.raises(TypeError):
+        AutoModel(model_dir=str(tmp_path))
