@@ -7,6 +7,7 @@
 // from hifigan/generator.py:110-117, 682-700.
 #include "conv.h"
 #include "runtime.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
@@ -161,7 +162,10 @@ int conv1d_f32_direct(const ConvDesc& d, const ConvW& w, hipStream_t st) {
 // LDS row pitch in bytes: the staged channels as bf16 + a 16-B pad against bank conflicts
 static __host__ __device__ inline int mf_rowb(int cin_gp) { return (cin_gp < MF_CC ? cin_gp : MF_CC) * 2 + 16; }
 
-template <int WAVES_P, int WAVES_C, bool PRECISE>
+// NK: 16-wide k steps per staged channel chunk when that is the same for every chunk of the launch (4, 6, 8);
+// 0 = decided at run time (odd channel counts of reduced-size models).  A compile-time NK and clamped addresses
+// keep the hot loops free of branches, so the compiler batches their loads instead of waiting on each one.
+template <int WAVES_P, int WAVES_C, bool PRECISE, int NK>
 __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(ConvDesc d, const bf16_t* __restrict__ wp, int nrows_max) {
     constexpr int TP = WAVES_P * 64, TCO = WAVES_C * 64, NT = WAVES_P * WAVES_C * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];    // hi tile [nrows_max][MF_ROWB] (+ lo tile when PRECISE)
@@ -202,62 +206,72 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
         const int q4 = ccn / 4;
         __syncthreads();
         // branch-free and unrolled: out-of-range rows / channels read a clamped address and are zeroed by a select,
-        // so the compiler keeps several of a thread's loads in flight instead of one wait per item
+        // and the activation kind is a compile-time constant of the loop body, so several loads stay in flight
         const int total = nrows * q4;
         const bool q4_pow2 = (q4 & (q4 - 1)) == 0;
         const int q4_sh = 31 - __clz(q4);
         const int row_max = max(n_in - 1, 0), ci_max = max(Cin_g - 4, 0);
+        auto stage = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll 4
-        for (int idx = tid; idx < total; idx += NT) {
-            const int r = q4_pow2 ? (idx >> q4_sh) : idx / q4;
-            const int c4 = (idx - r * q4) * 4;
-            const int row = row_lo + r, ci = ci0 + c4;
-            const bool ok = row >= 0 && row < n_in && ci < Cin_g;
-            float4 v = *reinterpret_cast<const float4*>(xb + (long)min(max(row, 0), row_max) * d.x_ld + ci_base + min(ci, ci_max));
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d.pre_act == ACT_LEAKY) {
-                v.x = act_leaky(v.x, d.pre_slope); v.y = act_leaky(v.y, d.pre_slope);
-                v.z = act_leaky(v.z, d.pre_slope); v.w = act_leaky(v.w, d.pre_slope);
-            } else if (d.pre_act == ACT_SNAKE) {
-                float4 a = *reinterpret_cast<const float4*>(d.alpha + ci_base + min(ci, ci_max));
-                if (PRECISE) {
-                    v.x = act_snake(v.x, a.x); v.y = act_snake(v.y, a.y);
-                    v.z = act_snake(v.z, a.z); v.w = act_snake(v.w, a.w);
-                } else {
-                    // the operand is rounded to bf16 next: hardware sine / reciprocal (~1e-6) are ample
-                    v.x = snake_fast(v.x, a.x); v.y = snake_fast(v.y, a.y);
-                    v.z = snake_fast(v.z, a.z); v.w = snake_fast(v.w, a.w);
+            for (int idx = tid; idx < total; idx += NT) {
+                const int r = q4_pow2 ? (idx >> q4_sh) : idx / q4;
+                const int c4 = (idx - r * q4) * 4;
+                const int row = row_lo + r, ci = ci0 + c4;
+                const bool ok = row >= 0 && row < n_in && ci < Cin_g;
+                float4 v = *reinterpret_cast<const float4*>(xb + (long)min(max(row, 0), row_max) * d.x_ld + ci_base + min(ci, ci_max));
+                float4 a = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (ACT == ACT_SNAKE) a = *reinterpret_cast<const float4*>(d.alpha + ci_base + min(ci, ci_max));
+                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ACT == ACT_LEAKY) {
+                    v.x = act_leaky(v.x, d.pre_slope); v.y = act_leaky(v.y, d.pre_slope);
+                    v.z = act_leaky(v.z, d.pre_slope); v.w = act_leaky(v.w, d.pre_slope);
+                } else if (ACT == ACT_SNAKE) {
+                    if (PRECISE) {
+                        v.x = act_snake(v.x, a.x); v.y = act_snake(v.y, a.y);
+                        v.z = act_snake(v.z, a.z); v.w = act_snake(v.w, a.w);
+                    } else {
+                        // the operand is rounded to bf16 next: hardware sine / reciprocal (~1e-6) are ample
+                        v.x = snake_fast(v.x, a.x); v.y = snake_fast(v.y, a.y);
+                        v.z = snake_fast(v.z, a.z); v.w = snake_fast(v.w, a.w);
+                    }
                 }
-            }
-            bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
-            uint2 pk;
-            pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
-            pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
-            *reinterpret_cast<uint2*>(smem + (size_t)r * MF_ROWB + c4 * 2) = pk;
-            if (PRECISE) {
-                bf16_t l0 = f32_to_bf16(v.x - bf16_to_f32(h0)), l1 = f32_to_bf16(v.y - bf16_to_f32(h1));
-                bf16_t l2 = f32_to_bf16(v.z - bf16_to_f32(h2)), l3 = f32_to_bf16(v.w - bf16_to_f32(h3));
-                pk.x = (uint32_t)l0 | ((uint32_t)l1 << 16);
-                pk.y = (uint32_t)l2 | ((uint32_t)l3 << 16);
-                *reinterpret_cast<uint2*>(lo_tile + (size_t)r * MF_ROWB + c4 * 2) = pk;
-            }
-        }
-        __syncthreads();
-        if (!wave_live) continue;
-        const int c16_0 = ci0 / 16, nk = ccn / 16;           // nk <= MF_CC/16 = 8
-        // weights of one tap (all k-steps of this channel chunk, two 32-column tiles) are requested as one batch,
-        // one tap ahead of the MFMAs that use them: L2 latency is paid once per tap, under the previous tap's math
-        auto load_b = [&](int t, frag_ab (&bb)[MF_CC / 16][2]) {
-            const bf16_t* wt = wp + ((((long)g * d.KW + t) * C16 + c16_0) * N32 + n32_base) * 512 + lane * 8;
-#pragma unroll
-            for (int kk = 0; kk < MF_CC / 16; ++kk) {
-                if (kk < nk) {
-                    bb[kk][0] = *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512);
-                    bb[kk][1] = tile1_live ? *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512 + 512) : bb[kk][0];
+                bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
+                uint2 pk;
+                pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+                *reinterpret_cast<uint2*>(smem + (size_t)r * MF_ROWB + c4 * 2) = pk;
+                if (PRECISE) {
+                    bf16_t l0 = f32_to_bf16(v.x - bf16_to_f32(h0)), l1 = f32_to_bf16(v.y - bf16_to_f32(h1));
+                    bf16_t l2 = f32_to_bf16(v.z - bf16_to_f32(h2)), l3 = f32_to_bf16(v.w - bf16_to_f32(h3));
+                    pk.x = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                    pk.y = (uint32_t)l2 | ((uint32_t)l3 << 16);
+                    *reinterpret_cast<uint2*>(lo_tile + (size_t)r * MF_ROWB + c4 * 2) = pk;
                 }
             }
         };
-        auto tap = [&](int t, const frag_ab (&bb)[MF_CC / 16][2]) {
+        if (d.pre_act == ACT_SNAKE) stage(std::integral_constant<int, ACT_SNAKE>{});
+        else if (d.pre_act == ACT_LEAKY) stage(std::integral_constant<int, ACT_LEAKY>{});
+        else stage(std::integral_constant<int, ACT_NONE>{});
+        __syncthreads();
+        if (!wave_live) continue;
+        const int c16_0 = ci0 / 16, nk = NK ? NK : ccn / 16;  // nk <= MF_CC/16 = 8
+        constexpr int KMAX = NK ? NK : MF_CC / 16;
+        const int t1off = tile1_live ? 512 : 0;               // a dead second tile re-reads the first: no branch
+        // weights stream from L2 in half-tap batches (KH k-steps x two 32-column tiles), one batch ahead of the
+        // MFMAs that use them; two batches of registers only, so two workgroups still fit a CU
+        constexpr int KH = KMAX / 2;
+        auto load_b = [&](int t, int half, frag_ab (&bb)[KH][2]) {
+            const bf16_t* wt = wp + ((((long)g * d.KW + t) * C16 + c16_0 + half * KH) * N32 + n32_base) * 512 + lane * 8;
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) {
+                if (NK || half * KH + kk < nk) {
+                    bb[kk][0] = *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512);
+                    bb[kk][1] = *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512 + t1off);
+                }
+            }
+        };
+        auto tap_half = [&](int t, int half, const frag_ab (&bb)[KH][2]) {
             int arow[2];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
@@ -265,11 +279,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
                 arow[mi] = ((d.up == 1) ? s : floordiv(s, d.up)) - row_lo;
             }
 #pragma unroll
-            for (int kk = 0; kk < MF_CC / 16; ++kk) {
-                if (kk < nk) {
+            for (int kk = 0; kk < KH; ++kk) {
+                if (NK || half * KH + kk < nk) {
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi) {
-                        size_t off = (size_t)arow[mi] * MF_ROWB + (kk * 16 + kh * 8) * 2;
+                        size_t off = (size_t)arow[mi] * MF_ROWB + ((half * KH + kk) * 16 + kh * 8) * 2;
                         frag_ab a = *reinterpret_cast<const frag_ab*>(smem + off);
                         acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb[kk][0], acc[mi][0], 0, 0, 0);
                         acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb[kk][1], acc[mi][1], 0, 0, 0);
@@ -282,15 +296,13 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
                 }
             }
         };
-        frag_ab b0[MF_CC / 16][2], b1[MF_CC / 16][2];
-        load_b(0, b0);
-        for (int t = 0; t < d.KW; t += 2) {
-            if (t + 1 < d.KW) load_b(t + 1, b1);
-            tap(t, b0);
-            if (t + 1 < d.KW) {
-                if (t + 2 < d.KW) load_b(t + 2, b0);
-                tap(t + 1, b1);
-            }
+        frag_ab h0[KH][2], h1[KH][2];
+        load_b(0, 0, h0);
+        for (int t = 0; t < d.KW; ++t) {
+            load_b(t, 1, h1);
+            tap_half(t, 0, h0);
+            if (t + 1 < d.KW) load_b(t + 1, 0, h0);
+            tap_half(t, 1, h1);
         }
     }
     if (!wave_live) return;
@@ -333,22 +345,35 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
     }
 }
 
-template <int WP, int WC, bool PR>
-static int launch_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st) {
-    constexpr int TP = WP * 64, TCO = WC * 64;
-    int nrows_max = (TP - 1 + (d.KW - 1) * d.dil) / d.up + 3;
-    const int Cin_gp = ((d.Cin / d.groups + 15) / 16) * 16;
-    size_t lds = (size_t)nrows_max * mf_rowb(Cin_gp) * (PR ? 2 : 1);
-    FY_CHECK(lds <= 160 * 1024, FY_ERR_ARG, "conv1d_bf16_mfma: input tile needs %zu B of LDS", lds);
+template <int WP, int WC, bool PR, int NK>
+static int launch_mfma2(const ConvDesc& d, const ConvW& w, int nrows_max, size_t lds, hipStream_t st) {
     int Cout_g = d.Cout / d.groups;
-    dim3 grid(cdiv(d.L_out, TP), d.groups * cdiv(Cout_g, TCO), d.B);
-    auto kern = conv1d_bf16_mfma_k<WP, WC, PR>;
-    ProfScope prof("conv_mfma", 2.0 * d.B * d.L_out * (double)d.Cout * (d.Cin / d.groups) * d.KW, st);
+    dim3 grid(cdiv(d.L_out, WP * 64), d.groups * cdiv(Cout_g, WC * 64), d.B);
+    auto kern = conv1d_bf16_mfma_k<WP, WC, PR, NK>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(WP * WC * 64), lds, st, d, w.w_mfma, nrows_max);
     HIP_TRY(hipGetLastError());
     return FY_OK;
+}
+
+template <int WP, int WC, bool PR>
+static int launch_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st) {
+    constexpr int TP = WP * 64;
+    int nrows_max = (TP - 1 + (d.KW - 1) * d.dil) / d.up + 3;
+    const int Cin_gp = ((d.Cin / d.groups + 15) / 16) * 16;
+    size_t lds = (size_t)nrows_max * mf_rowb(Cin_gp) * (PR ? 2 : 1);
+    FY_CHECK(lds <= 160 * 1024, FY_ERR_ARG, "conv1d_bf16_mfma: input tile needs %zu B of LDS", lds);
+    ProfScope prof("conv_mfma", 2.0 * d.B * d.L_out * (double)d.Cout * (d.Cin / d.groups) * d.KW, st);
+    // every staged chunk has the same number of k steps when Cin_gp <= 128 or Cin_gp is a multiple of 128
+    int nk = 0;
+    if (Cin_gp <= MF_CC) nk = Cin_gp / 16; else if (Cin_gp % MF_CC == 0) nk = MF_CC / 16;
+    switch (nk) {
+        case 4: return launch_mfma2<WP, WC, PR, 4>(d, w, nrows_max, lds, st);
+        case 6: return launch_mfma2<WP, WC, PR, 6>(d, w, nrows_max, lds, st);
+        case 8: return launch_mfma2<WP, WC, PR, 8>(d, w, nrows_max, lds, st);
+        default: return launch_mfma2<WP, WC, PR, 0>(d, w, nrows_max, lds, st);
+    }
 }
 
 int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_t st) {
