@@ -213,40 +213,55 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
         const int row_max = max(n_in - 1, 0), ci_max = max(Cin_g - 4, 0);
         auto stage = [&](auto act_tag) {
             constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll 4
-            for (int idx = tid; idx < total; idx += NT) {
-                const int r = q4_pow2 ? (idx >> q4_sh) : idx / q4;
-                const int c4 = (idx - r * q4) * 4;
-                const int row = row_lo + r, ci = ci0 + c4;
-                const bool ok = row >= 0 && row < n_in && ci < Cin_g;
-                float4 v = *reinterpret_cast<const float4*>(xb + (long)min(max(row, 0), row_max) * d.x_ld + ci_base + min(ci, ci_max));
-                float4 a = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (ACT == ACT_SNAKE) a = *reinterpret_cast<const float4*>(d.alpha + ci_base + min(ci, ci_max));
-                if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ACT == ACT_LEAKY) {
-                    v.x = act_leaky(v.x, d.pre_slope); v.y = act_leaky(v.y, d.pre_slope);
-                    v.z = act_leaky(v.z, d.pre_slope); v.w = act_leaky(v.w, d.pre_slope);
-                } else if (ACT == ACT_SNAKE) {
-                    if (PRECISE) {
-                        v.x = act_snake(v.x, a.x); v.y = act_snake(v.y, a.y);
-                        v.z = act_snake(v.z, a.z); v.w = act_snake(v.w, a.w);
-                    } else {
-                        // the operand is rounded to bf16 next: hardware sine / reciprocal (~1e-6) are ample
-                        v.x = snake_fast(v.x, a.x); v.y = snake_fast(v.y, a.y);
-                        v.z = snake_fast(v.z, a.z); v.w = snake_fast(v.w, a.w);
-                    }
+            constexpr int SB = 4;                              // items per batch: SB (x2 with Snake) loads in flight per thread
+            for (int base = tid; base < total; base += NT * SB) {
+                float4 vv[SB], aa[SB];
+                int rr[SB], cc[SB];
+                bool okk[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int idx = min(base + u * NT, total - 1);
+                    const int r = q4_pow2 ? (idx >> q4_sh) : idx / q4;
+                    const int c4 = (idx - r * q4) * 4;
+                    const int row = row_lo + r, ci = ci0 + c4;
+                    rr[u] = r; cc[u] = c4;
+                    okk[u] = row >= 0 && row < n_in && ci < Cin_g;
+                    vv[u] = *reinterpret_cast<const float4*>(xb + (long)min(max(row, 0), row_max) * d.x_ld + ci_base + min(ci, ci_max));
+                    aa[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (ACT == ACT_SNAKE) aa[u] = *reinterpret_cast<const float4*>(d.alpha + ci_base + min(ci, ci_max));
                 }
-                bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
-                uint2 pk;
-                pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
-                *reinterpret_cast<uint2*>(smem + (size_t)r * MF_ROWB + c4 * 2) = pk;
-                if (PRECISE) {
-                    bf16_t l0 = f32_to_bf16(v.x - bf16_to_f32(h0)), l1 = f32_to_bf16(v.y - bf16_to_f32(h1));
-                    bf16_t l2 = f32_to_bf16(v.z - bf16_to_f32(h2)), l3 = f32_to_bf16(v.w - bf16_to_f32(h3));
-                    pk.x = (uint32_t)l0 | ((uint32_t)l1 << 16);
-                    pk.y = (uint32_t)l2 | ((uint32_t)l3 << 16);
-                    *reinterpret_cast<uint2*>(lo_tile + (size_t)r * MF_ROWB + c4 * 2) = pk;
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    if (base + u * NT >= total) break;
+                    float4 v = vv[u];
+                    const float4 a = aa[u];
+                    const int r = rr[u], c4 = cc[u];
+                    if (!okk[u]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ACT == ACT_LEAKY) {
+                        v.x = act_leaky(v.x, d.pre_slope); v.y = act_leaky(v.y, d.pre_slope);
+                        v.z = act_leaky(v.z, d.pre_slope); v.w = act_leaky(v.w, d.pre_slope);
+                    } else if (ACT == ACT_SNAKE) {
+                        if (PRECISE) {
+                            v.x = act_snake(v.x, a.x); v.y = act_snake(v.y, a.y);
+                            v.z = act_snake(v.z, a.z); v.w = act_snake(v.w, a.w);
+                        } else {
+                            // the operand is rounded to bf16 next: hardware sine / reciprocal (~1e-6) are ample
+                            v.x = snake_fast(v.x, a.x); v.y = snake_fast(v.y, a.y);
+                            v.z = snake_fast(v.z, a.z); v.w = snake_fast(v.w, a.w);
+                        }
+                    }
+                    bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
+                    uint2 pk;
+                    pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                    pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+                    *reinterpret_cast<uint2*>(smem + (size_t)r * MF_ROWB + c4 * 2) = pk;
+                    if (PRECISE) {
+                        bf16_t l0 = f32_to_bf16(v.x - bf16_to_f32(h0)), l1 = f32_to_bf16(v.y - bf16_to_f32(h1));
+                        bf16_t l2 = f32_to_bf16(v.z - bf16_to_f32(h2)), l3 = f32_to_bf16(v.w - bf16_to_f32(h3));
+                        pk.x = (uint32_t)l0 | ((uint32_t)l1 << 16);
+                        pk.y = (uint32_t)l2 | ((uint32_t)l3 << 16);
+                        *reinterpret_cast<uint2*>(lo_tile + (size_t)r * MF_ROWB + c4 * 2) = pk;
+                    }
                 }
             }
         };
