@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -120,16 +121,26 @@ def main():
             gather_audio(wav, samples)          # RCCL over xGMI: the finished audio of every rank, on every rank
         return samples
 
-    for i in range(a.warmup):
-        samples = step()
+    def run(k):
+        """k steps.  Consecutive steps are software-pipelined over two HIP streams (the LM of step i+1 beside the
+        flow decoder + vocoder of step i); every step still runs the whole path on its own batch."""
+        if a.no_pipeline:
+            return [step() for _ in range(k)][-1]
+        samples = None
+        for wav, samples, _ in model.tts_pipeline([inputs] * k, min_len=[forced] * k, max_len=[forced] * k, keep_on_device=True):
+            if world > 1:
+                gather_audio(wav, samples)
+        return samples
+
+    if a.warmup:
+        samples = run(a.warmup)
         torch.cuda.synchronize()
-        log(f"warmup step {i} done")
+        log(f"{a.warmup} warmup steps done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        samples = step()
+    samples = run(a.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -141,6 +152,12 @@ def main():
     audio_per_step = world * sum(samples) / 24000.0
     value = audio_per_step * a.steps / dt
     log(f"timed {a.steps} steps: {1e3 * dt / a.steps:.1f} ms/step, {value:.1f} audio_s/s")
+    # un-pipelined latency of one batch, for reference
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    latency_ms = 1e3 * (time.perf_counter() - t1)
 
     # roofline leg: one more step with HIP events around every launch of the dominant kernel
     L = _lib.lib()
@@ -173,6 +190,7 @@ def main():
         "config": {"workload": "CosyVoice3-0.5B instruct (inference_instruct2), batch 8 mixed-length utterances per GPU, "
                                "5 s prompt, 75 forced speech tokens (3 s) each, LM greedy -> 10-step CFG flow (DiT-22) -> HiFT",
                    "batch_per_gpu": BATCH, "tokens_per_utt": N_TOK, "prompt_tokens": P_TOK, "parallelism": f"dp{world}",
+                   "steps_pipelined": not a.no_pipeline, "batch_latency_ms_unpipelined": round(latency_ms, 1),
                    "weights": "random-init, CosyVoice3-0.5B shapes (859 M params)"},
         "roofline": roofline,
     }

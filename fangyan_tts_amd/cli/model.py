@@ -61,26 +61,79 @@ class CosyVoice3Model:
             n_tok = out_n.cpu().tolist()
             if min(n_tok) < 1:
                 raise RuntimeError("the language model emitted no speech token for an utterance")
-            fp = [d["flow_prompt_speech_token"].reshape(-1) for d in inputs]
-            pf = [d["prompt_speech_feat"].reshape(-1, 80) for d in inputs]
-            Pmax, PMmax = max(max(len(t) for t in fp), 1), max(max(f.shape[0] for f in pf), 1)
-            ptok = torch.zeros(B, Pmax, dtype=torch.int32)
-            pfeat = torch.zeros(B, PMmax, 80)
-            for b in range(B):
-                ptok[b, : len(fp[b])] = fp[b].to(torch.int32)
-                pfeat[b, : pf[b].shape[0]] = pf[b]
-            emb = torch.cat([d["flow_embedding"].reshape(1, -1) for d in inputs]).float()
-            mel = self.flow.inference(out, n_tok, ptok, [len(t) for t in fp], pfeat, [f.shape[0] for f in pf], emb, self.rand_noise)
-            frames = [2 * n for n in n_tok]
-            if speed != 1.0:                                    # cli/model.py:435-437
-                assert B == 1, "speed change only supports a single utterance"
-                mel = torch.nn.functional.interpolate(mel, size=int(mel.shape[2] / speed), mode="linear").contiguous()
-                frames = [mel.shape[2]]
-            wav, _ = self.hift.inference(mel, self.rand_ini, self.sine_noise, frames=frames)
-            self.last_mel, self.last_frames = mel, frames        # kept for parity tests / debugging
-        samples = [f * self.cfg.hift.upsample_total for f in frames]
+            wav, samples = self._token2wav(inputs, out, n_tok, speed)
         toks = [out[b, : n_tok[b]] for b in range(B)]
         return (wav if keep_on_device else wav.cpu()), samples, toks
+
+    # ------------------------------------------------------------------ pipelined batches
+    @torch.inference_mode()
+    def tts_pipeline(self, batches: Sequence[Sequence[Dict[str, torch.Tensor]]], min_len=None, max_len=None,
+                     keep_on_device: bool = False):
+        """Consecutive batches, software-pipelined over two HIP streams: the speech-token LM of batch i+1
+        (latency-bound, a few workgroups per launch) runs beside the flow decoder + vocoder of batch i
+        (throughput-bound).  Yields (wav, n_samples, tokens) per batch, in order.  Same results as tts_batch."""
+        import queue
+        import threading as th
+        dev = self.device
+        s_llm = torch.cuda.Stream(device=dev, priority=-1)
+        s_fv = torch.cuda.Stream(device=dev)
+        q: "queue.Queue" = queue.Queue(maxsize=2)
+        z = torch.zeros(1, 0, dtype=torch.int32)
+
+        def producer():
+            try:
+                with torch.cuda.device(dev), torch.cuda.stream(s_llm):
+                    for bi, inputs in enumerate(batches):
+                        text = [d["text"].reshape(-1).tolist() for d in inputs]
+                        ptext = [d.get("prompt_text", z).reshape(-1).tolist() for d in inputs]
+                        pspeech = [d.get("llm_prompt_speech_token", z).reshape(-1).tolist() for d in inputs]
+                        mn = min_len[bi] if min_len is not None else None
+                        mx = max_len[bi] if max_len is not None else None
+                        out, out_n, _ = self.llm.generate(text, ptext, pspeech, min_len=mn, max_len=mx)
+                        n_tok = out_n.cpu().tolist()              # synchronises s_llm: the ids are complete
+                        q.put((inputs, out, n_tok))
+                q.put(None)
+            except BaseException as e:                             # surface in the consumer
+                q.put(e)
+
+        t = th.Thread(target=producer, daemon=True)
+        with self.lock:
+            t.start()
+            with torch.cuda.stream(s_fv):
+                while True:
+                    item = q.get()
+                    if item is None:
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    inputs, out, n_tok = item
+                    if min(n_tok) < 1:
+                        raise RuntimeError("the language model emitted no speech token for an utterance")
+                    wav, samples = self._token2wav(inputs, out, n_tok, 1.0)
+                    s_fv.synchronize()
+                    yield (wav if keep_on_device else wav.cpu()), samples, [out[b, : n_tok[b]] for b in range(len(inputs))]
+            t.join()
+
+    def _token2wav(self, inputs, out, n_tok, speed):
+        B = len(inputs)
+        fp = [d["flow_prompt_speech_token"].reshape(-1) for d in inputs]
+        pf = [d["prompt_speech_feat"].reshape(-1, 80) for d in inputs]
+        Pmax, PMmax = max(max(len(t) for t in fp), 1), max(max(f.shape[0] for f in pf), 1)
+        ptok = torch.zeros(B, Pmax, dtype=torch.int32)
+        pfeat = torch.zeros(B, PMmax, 80)
+        for b in range(B):
+            ptok[b, : len(fp[b])] = fp[b].to(torch.int32)
+            pfeat[b, : pf[b].shape[0]] = pf[b]
+        emb = torch.cat([d["flow_embedding"].reshape(1, -1) for d in inputs]).float()
+        mel = self.flow.inference(out, n_tok, ptok, [len(t) for t in fp], pfeat, [f.shape[0] for f in pf], emb, self.rand_noise)
+        frames = [2 * n for n in n_tok]
+        if speed != 1.0:                                    # cli/model.py:435-437
+            assert B == 1, "speed change only supports a single utterance"
+            mel = torch.nn.functional.interpolate(mel, size=int(mel.shape[2] / speed), mode="linear").contiguous()
+            frames = [mel.shape[2]]
+        wav, _ = self.hift.inference(mel, self.rand_ini, self.sine_noise, frames=frames)
+        self.last_mel, self.last_frames = mel, frames        # kept for parity tests / debugging
+        return wav, [f * self.cfg.hift.upsample_total for f in frames]
 
     # ------------------------------------------------------------------ reference-shaped path
     def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192), llm_embedding=torch.zeros(0, 192),

@@ -113,3 +113,17 @@ def test_full_size_against_reference_fixture():
     wav, samples, toks = m.tts_batch([inp])
     assert toks[0].cpu().tolist() == f[f"c{ctag}.tokens"].tolist()
     wav_checks(m, cfg, sd[2], wav, samples[0], f, ctag, ri, sn, "full")
+
+
+def test_pipeline_equals_batches(tiny):
+    """tts_pipeline (LM of batch i+1 beside flow + vocoder of batch i on two streams) returns what tts_batch returns."""
+    m, cfg, sd, ri, sn = tiny
+    ins = [e2e_input(cfg, *c)[0] for c in CASES]
+    batches = [[ins[0]], [ins[1], ins[0]], [ins[1]]]
+    ref = [m.tts_batch(b) for b in batches]
+    got = list(m.tts_pipeline(batches))
+    assert len(got) == len(ref)
+    for (w, s, t), (w2, s2, t2) in zip(got, ref):
+        assert s == s2 and all(torch.equal(a, b) for a, b in zip(t, t2))
+        for b in range(len(s)):
+            assert maxerr(w[b, : s[b]], w2[b, : s2[b]]) < 1e-5
