@@ -18,7 +18,20 @@ inputs = bench.make_inputs(cfg, 0)
 text = [d["text"].reshape(-1).tolist() for d in inputs]; ptext = [d["prompt_text"].reshape(-1).tolist() for d in inputs]
 ptok = torch.cat([d["flow_prompt_speech_token"] for d in inputs]).to(torch.int32).to(dev); pfeat = torch.cat([d["prompt_speech_feat"] for d in inputs]).to(dev)
 emb = torch.cat([d["flow_embedding"] for d in inputs]).to(dev)
-s_llm = torch.cuda.Stream(device=dev, priority=-1); s_fh = torch.cuda.Stream(device=dev)
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+def masked_stream(exclude):
+    """a HIP stream whose kernels may not use the first `exclude` CUs (bit i of the mask = CU i enabled)"""
+    words = (ctypes.c_uint32 * 8)(*([0xFFFFFFFF] * 8))
+    for i in range(exclude):
+        words[i // 32] &= ~(1 << (i % 32))
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+    assert rc == 0, rc
+    return torch.cuda.ExternalStream(st.value, device=dev)
+EXCL = int(os.environ.get("EXCL", "0"))
+s_llm = torch.cuda.Stream(device=dev, priority=-1); s_fh = masked_stream(EXCL) if EXCL else torch.cuda.Stream(device=dev)
+print("flow stream excluded CUs:", EXCL, flush=True)
 
 def run_llm():
     with torch.cuda.stream(s_llm):
@@ -41,5 +54,8 @@ for rep in range(3):
     t0 = time.perf_counter()
     res = {}
     ta = threading.Thread(target=lambda: res.__setitem__("o", run_llm())); tb = threading.Thread(target=lambda: res.__setitem__("w", run_fh(out)))
-    ta.start(); tb.start(); ta.join(); t1 = time.perf_counter(); tb.join(); t2 = time.perf_counter()
-    print(f"overlapped: llm done at {1e3*(t1-t0):.1f} ms, both done at {1e3*(t2-t0):.1f} ms", flush=True)
+    tdone = {}
+    ta = threading.Thread(target=lambda: (res.__setitem__("o", run_llm()), tdone.__setitem__("l", time.perf_counter())))
+    tb = threading.Thread(target=lambda: (res.__setitem__("w", run_fh(out)), tdone.__setitem__("f", time.perf_counter())))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    print(f"overlapped: llm done at {1e3*(tdone['l']-t0):.1f} ms, flow+hift done at {1e3*(tdone['f']-t0):.1f} ms", flush=True)
