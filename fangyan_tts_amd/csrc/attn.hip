@@ -213,78 +213,99 @@ int llm_attention(const float* q, int q_ld, const float* Kc, const float* Vc, co
 // positions 0..pos in one launch.  qkv: fp32 [R][(Hq+2Hk)*64] raw projections of the current token;
 // the new key/value never round-trip through the cache inside the step (each block rotates its own
 // copy; the first query head of a kv group writes it for later steps).
-__global__ __launch_bounds__(64) void llm_attention_step_k(const float* __restrict__ qkv, float* __restrict__ Kc, float* __restrict__ Vc,
-                                                           const int* __restrict__ row_seq, const int* __restrict__ row_pos,
-                                                           const float* __restrict__ inv_freq, float* __restrict__ out, int o_ld,
-                                                           int Hq, int Hk, int max_ctx, float scale) {
-    extern __shared__ float sh[];             // [64] q + [max_ctx] scores
+__global__ __launch_bounds__(256) void llm_attention_step_k(const float* __restrict__ qkv, float* __restrict__ Kc, float* __restrict__ Vc,
+                                                            const int* __restrict__ row_seq, const int* __restrict__ row_pos,
+                                                            const float* __restrict__ inv_freq, float* __restrict__ out, int o_ld,
+                                                            int Hq, int Hk, int max_ctx, float scale) {
+    // 4 waves per (row, query head): every wave rotates q / the new k itself (64 lanes = 64 dims); the cached keys
+    // are spread one per thread, the value rows in four contiguous quarters, partial sums meet in LDS.
+    extern __shared__ float sh[];             // [64] q + [max_ctx] scores + [4][64] partial outputs + [8] reductions
     float* qs = sh;
     float* sc = sh + 64;
-    const int r = blockIdx.x, hq = blockIdx.y, lane = threadIdx.x;
+    float* part = sc + max_ctx;
+    float* redm = part + 256;
+    const int r = blockIdx.x, hq = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int seq = row_seq[r], pos = row_pos[r];
     const int grp = Hq / Hk, hk = hq / grp;
     const int ld = (Hq + 2 * Hk) * 64;
     const float* row = qkv + (long)r * ld;
-    const float ang = (float)pos * inv_freq[lane & 31];
-    const float cs = cosf(ang), sn = sinf(ang);
     const float qv = row[hq * 64 + lane], kv = row[(Hq + hk) * 64 + lane], vv = row[(Hq + Hk + hk) * 64 + lane];
+    const float ang = (float)pos * inv_freq[lane & 31];
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
     const float qo = __shfl_xor(qv, 32, 64), ko = __shfl_xor(kv, 32, 64);
     const float qr = lane < 32 ? qv * cs - qo * sn : qv * cs + qo * sn;
     const float kr = lane < 32 ? kv * cs - ko * sn : kv * cs + ko * sn;
     float* Kb = Kc + ((long)seq * Hk + hk) * max_ctx * 64;
     float* Vb = Vc + ((long)seq * Hk + hk) * max_ctx * 64;
-    if (hq % grp == 0) {
-        Kb[(long)pos * 64 + lane] = kr;
-        Vb[(long)pos * 64 + lane] = vv;
+    if (wid == 0) {
+        if (hq % grp == 0) {
+            Kb[(long)pos * 64 + lane] = kr;
+            Vb[(long)pos * 64 + lane] = vv;
+        }
+        qs[lane] = qr;
     }
-    qs[lane] = qr;
     __syncthreads();
     const float s_new = wave_sum(qr * kr) * scale;
     float mx = s_new;
-    for (int j = lane; j < pos; j += 64) {
+    for (int j = tid; j < pos; j += 256) {
         const float4* kp = reinterpret_cast<const float4*>(Kb + (long)j * 64);
+        float4 k4[16];
+#pragma unroll
+        for (int d4 = 0; d4 < 16; ++d4) k4[d4] = kp[d4];
         float s = 0.f;
 #pragma unroll
         for (int d4 = 0; d4 < 16; ++d4) {
-            float4 k4 = kp[d4];
-            s = fmaf(qs[d4 * 4 + 0], k4.x, s);
-            s = fmaf(qs[d4 * 4 + 1], k4.y, s);
-            s = fmaf(qs[d4 * 4 + 2], k4.z, s);
-            s = fmaf(qs[d4 * 4 + 3], k4.w, s);
+            s = fmaf(qs[d4 * 4 + 0], k4[d4].x, s);
+            s = fmaf(qs[d4 * 4 + 1], k4[d4].y, s);
+            s = fmaf(qs[d4 * 4 + 2], k4[d4].z, s);
+            s = fmaf(qs[d4 * 4 + 3], k4[d4].w, s);
         }
         s *= scale;
         sc[j] = s;
         mx = fmaxf(mx, s);
     }
     mx = wave_max(mx);
+    if (lane == 0) redm[wid] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
     float sum = 0.f;
-    for (int j = lane; j < pos; j += 64) {
+    for (int j = tid; j < pos; j += 256) {
         float p = expf(sc[j] - mx);
         sc[j] = p;
         sum += p;
     }
-    const float p_new = expf(s_new - mx);
-    sum = wave_sum(sum) + p_new;
+    sum = wave_sum(sum);
+    if (lane == 0) redm[4 + wid] = sum;
     __syncthreads();
-    float acc = p_new * vv;
-    int j = 0;
-    for (; j + 4 <= pos; j += 4) {           // four independent loads in flight per trip
-        float v0 = Vb[(long)j * 64 + lane], v1 = Vb[(long)(j + 1) * 64 + lane], v2 = Vb[(long)(j + 2) * 64 + lane], v3 = Vb[(long)(j + 3) * 64 + lane];
-        acc = fmaf(sc[j], v0, acc);
-        acc = fmaf(sc[j + 1], v1, acc);
-        acc = fmaf(sc[j + 2], v2, acc);
-        acc = fmaf(sc[j + 3], v3, acc);
+    const float p_new = expf(s_new - mx);
+    sum = ((redm[4] + redm[5]) + (redm[6] + redm[7])) + p_new;
+    // values: wave w owns positions [w*q4, (w+1)*q4)
+    const int q4 = (pos + 3) >> 2, j0 = wid * q4, j1 = min(pos, j0 + q4);
+    float acc = 0.f;
+    int j = j0;
+    for (; j + 8 <= j1; j += 8) {             // eight independent row loads in flight per trip
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = Vb[(long)(j + u) * 64 + lane];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(sc[j + u], v[u], acc);
     }
-    for (; j < pos; ++j) acc = fmaf(sc[j], Vb[(long)j * 64 + lane], acc);
-    out[(long)r * o_ld + hq * 64 + lane] = acc / sum;
+    for (; j < j1; ++j) acc = fmaf(sc[j], Vb[(long)j * 64 + lane], acc);
+    part[wid * 64 + lane] = acc;
+    __syncthreads();
+    if (wid == 0) {
+        float o = ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane])) + p_new * vv;
+        out[(long)r * o_ld + hq * 64 + lane] = o / sum;
+    }
 }
 
 int llm_attention_step(const float* qkv, float* Kc, float* Vc, const int* row_seq, const int* row_pos, const float* inv_freq,
                        float* out, int o_ld, int R, int Hq, int Hk, int max_ctx, hipStream_t st) {
     FY_CHECK(qkv && Kc && Vc && row_seq && row_pos && inv_freq && out && R >= 1 && Hq % Hk == 0, FY_ERR_ARG, "llm_attention_step: bad arguments");
-    size_t lds = (64 + (size_t)max_ctx) * sizeof(float);
+    size_t lds = (64 + (size_t)max_ctx + 256 + 8) * sizeof(float);
     FY_CHECK(lds <= 64 * 1024, FY_ERR_ARG, "llm_attention_step: context %d too long for the score buffer", max_ctx);
-    hipLaunchKernelGGL(llm_attention_step_k, dim3(R, Hq), dim3(64), lds, st, qkv, Kc, Vc, row_seq, row_pos, inv_freq, out, o_ld, Hq, Hk,
+    hipLaunchKernelGGL(llm_attention_step_k, dim3(R, Hq), dim3(256), lds, st, qkv, Kc, Vc, row_seq, row_pos, inv_freq, out, o_ld, Hq, Hk,
                        max_ctx, 0.125f);
     HIP_TRY(hipGetLastError());
     return FY_OK;

@@ -108,15 +108,25 @@ __global__ __launch_bounds__(256) void sample_k(const float* __restrict__ logits
     const int b = blockIdx.x, tid = threadIdx.x;
     if (st[3 * mb + b]) return;
     const float* x = logits + (long)b * n_all;
+    // the row is read once into registers (all loads in flight together), the three passes run on registers
+    constexpr int PER = 32;                                  // 256 x 32 = 8192 >= speech vocabulary + 200
+    float xv[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = tid + u * 256;
+        xv[u] = i < n_all ? x[i] : -3.0e38f;
+    }
     float mx = -3.0e38f;
-    for (int i = tid; i < n_all; i += 256) mx = fmaxf(mx, x[i]);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) mx = fmaxf(mx, xv[u]);
     sv[tid] = mx;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) sv[tid] = fmaxf(sv[tid], sv[tid + o]); __syncthreads(); }
     mx = sv[0];
     __syncthreads();
     float s = 0.f;
-    for (int i = tid; i < n_all; i += 256) s += expf(x[i] - mx);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) if (tid + u * 256 < n_all) s += expf(xv[u] - mx);
     sv[tid] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if (tid < o) sv[tid] += sv[tid + o]; __syncthreads(); }
@@ -126,10 +136,14 @@ __global__ __launch_bounds__(256) void sample_k(const float* __restrict__ logits
     const int lim = raw_n < st[5 * mb + b] ? n_real : n_all;       // eos forbidden below min_len
     float best = -3.0e38f;
     int bi = 0x7FFFFFFF;
-    for (int i = tid; i < n_all; i += 256) {
-        float lp = (x[i] - mx) - lse;
-        if (logp_keep && keep_step >= 0) logp_keep[((long)keep_step * mb + b) * n_all + i] = lp;
-        if (i < lim && (lp > best || (lp == best && i < bi))) { best = lp; bi = i; }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = tid + u * 256;
+        if (i < n_all) {
+            float lp = (xv[u] - mx) - lse;
+            if (logp_keep && keep_step >= 0) logp_keep[((long)keep_step * mb + b) * n_all + i] = lp;
+            if (i < lim && (lp > best || (lp == best && i < bi))) { best = lp; bi = i; }
+        }
     }
     sv[tid] = best; si[tid] = bi;
     __syncthreads();
@@ -331,6 +345,7 @@ static int llm_head_and_sample(fy_llm* l, int B, const float* rows, int32_t* out
     a.W = l->w_head; a.x = rows; a.ldx = H; a.R = B; a.N = NS; a.K = H; a.y = l->logits; a.ldy = NS;
     a.norm_w = l->norm_w; a.eps = c.rms_eps;
     FY_TRY(gemv_bf16w(a, st));
+    FY_CHECK(NS <= 256 * 32, FY_ERR_ARG, "sample: %d logits exceed the kernel's register tile", NS);
     hipLaunchKernelGGL(sample_k, dim3(B), dim3(256), 0, st, l->logits, NS, c.speech_tokens, l->st, l->max_batch, out_ids, out_ld,
                        l->speech_emb, l->h, H, l->logp_keep, keep_step < FY_LLM_KEEP_LOGP ? keep_step : -1);
     HIP_TRY(hipGetLastError());
