@@ -82,17 +82,27 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
+    ap.add_argument("--llm-streams", type=int, default=2, help="LM handles decoding different steps' batches concurrently")
+    ap.add_argument("--flow-cu-exclude", type=int, default=None, help="CUs kept clear of the flow / vocoder stream")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # FY_BENCH_REHEARSAL=1: several ranks share GPU 0 over gloo (a 1-GPU box cannot hold an RCCL group); the
+    # audio is gathered through host memory.  Only for exercising the N > 1 code path, never for numbers.
+    rehearsal = os.environ.get("FY_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from fangyan_tts_amd import _lib, build, synth
     from fangyan_tts_amd.cli.model import CosyVoice3Model
@@ -109,7 +119,7 @@ def main():
     ri = torch.from_numpy(synth.hift_rand_ini()).to(dev)
     sn = torch.from_numpy(synth.hift_sine_noise(2 * N_TOK * 480)).to(dev)
     model = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=BATCH, max_text=64, max_prompt_tokens=P_TOK,
-                            max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn)
+                            max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn, n_llm=1 if a.no_pipeline else a.llm_streams)
     log("engines ready")
     inputs = make_inputs(cfg, rank)
     forced = [N_TOK] * BATCH
@@ -118,7 +128,7 @@ def main():
     def step():
         wav, samples, _ = model.tts_batch(inputs, min_len=forced, max_len=forced, keep_on_device=True)
         if world > 1:
-            gather_audio(wav, samples)          # RCCL over xGMI: the finished audio of every rank, on every rank
+            gather_audio(wav.cpu() if rehearsal else wav, samples)    # RCCL over xGMI: every rank's finished audio, on every rank
         return samples
 
     def run(k):
@@ -127,9 +137,10 @@ def main():
         if a.no_pipeline:
             return [step() for _ in range(k)][-1]
         samples = None
-        for wav, samples, _ in model.tts_pipeline([inputs] * k, min_len=[forced] * k, max_len=[forced] * k, keep_on_device=True):
+        for wav, samples, _ in model.tts_pipeline([inputs] * k, min_len=[forced] * k, max_len=[forced] * k, keep_on_device=True,
+                                                  flow_cu_exclude=a.flow_cu_exclude):
             if world > 1:
-                gather_audio(wav, samples)
+                gather_audio(wav.cpu() if rehearsal else wav, samples)
         return samples
 
     if a.warmup:
@@ -146,7 +157,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     audio_per_step = world * sum(samples) / 24000.0
@@ -190,7 +201,7 @@ def main():
         "config": {"workload": "CosyVoice3-0.5B instruct (inference_instruct2), batch 8 mixed-length utterances per GPU, "
                                "5 s prompt, 75 forced speech tokens (3 s) each, LM greedy -> 10-step CFG flow (DiT-22) -> HiFT",
                    "batch_per_gpu": BATCH, "tokens_per_utt": N_TOK, "prompt_tokens": P_TOK, "parallelism": f"dp{world}",
-                   "steps_pipelined": not a.no_pipeline, "batch_latency_ms_unpipelined": round(latency_ms, 1),
+                   "steps_pipelined": not a.no_pipeline, "llm_streams": 1 if a.no_pipeline else a.llm_streams, "flow_cu_exclude": a.flow_cu_exclude, "batch_latency_ms_unpipelined": round(latency_ms, 1),
                    "weights": "random-init, CosyVoice3-0.5B shapes (859 M params)"},
         "roofline": roofline,
     }

@@ -23,15 +23,18 @@ class CosyVoice3Model:
                  hift_weights: Dict[str, torch.Tensor], cfg: ModelCfg = ModelCfg(), device: Optional[torch.device] = None,
                  max_batch: int = 8, max_text: int = 128, max_prompt_tokens: int = 800, max_tokens: int = 800,
                  rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
-                 sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False):
+                 sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False, n_llm: int = 1):
         if not torch.cuda.is_available():
             raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.cfg, self.fp16 = cfg, fp16
         self.max_batch, self.max_tokens, self.max_prompt_tokens = max_batch, max_tokens, max_prompt_tokens
         max_frames = 2 * (max_tokens + max_prompt_tokens)
-        self.llm = LlmEngine(llm_weights, cfg.llm, max_batch=max_batch, max_ctx=2 + max_text + max_prompt_tokens + max_tokens,
-                             device=self.device, keep_weights=keep_llm_weights)
+        # n_llm > 1: extra LM handles (own KV cache and workspace) so tts_pipeline can decode several batches at once;
+        # one decode stream uses a few dozen workgroups per launch and is bound by launch latency, not by the chip
+        self.llms = [LlmEngine(llm_weights, cfg.llm, max_batch=max_batch, max_ctx=2 + max_text + max_prompt_tokens + max_tokens,
+                               device=self.device, keep_weights=keep_llm_weights and i == 0) for i in range(max(1, n_llm))]
+        self.llm = self.llms[0]
         self.flow = FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device)
         self.hift = HiftEngine(hift_weights, cfg.hift, max_batch=max_batch, max_frames=2 * max_tokens, device=self.device)
         # The reference draws these buffers once at construction and never stores them in a checkpoint
@@ -68,46 +71,50 @@ class CosyVoice3Model:
     # ------------------------------------------------------------------ pipelined batches
     @torch.inference_mode()
     def tts_pipeline(self, batches: Sequence[Sequence[Dict[str, torch.Tensor]]], min_len=None, max_len=None,
-                     keep_on_device: bool = False, flow_cu_exclude: int = 80):
-        """Consecutive batches, software-pipelined over two HIP streams: the speech-token LM of batch i+1
-        (latency-bound, a few workgroups per launch) runs beside the flow decoder + vocoder of batch i
-        (throughput-bound).  Yields (wav, n_samples, tokens) per batch, in order.  Same results as tts_batch.
+                     keep_on_device: bool = False, flow_cu_exclude: Optional[int] = None):
+        """Consecutive batches, software-pipelined over HIP streams: the speech-token LM of the next batches
+        (latency-bound, a few workgroups per launch; one stream per LM handle, `n_llm` of them) runs beside the
+        flow decoder + vocoder of batch i (throughput-bound).  Yields (wav, n_samples, tokens) per batch, in
+        order.  Same results as tts_batch.
 
         flow_cu_exclude: CUs the flow / vocoder stream may NOT use (hipExtStreamCreateWithCUMask).  The LM's short
         kernels otherwise queue behind GEMM workgroups that hold every CU's LDS; measured on MI355X at batch 8 the
-        stage time is 136 ms with no mask and 119 ms with 80-96 CUs kept clear (0 disables the mask)."""
+        stage time with ONE LM handle is 137 ms with no mask and 126 ms with 80 CUs kept clear; with TWO LM handles
+        it is 106 ms with no mask and the mask only hurts (175-200 ms).  None = 80 for one handle, 0 (no mask) otherwise."""
         import queue
         import threading as th
         dev = self.device
-        s_llm = torch.cuda.Stream(device=dev, priority=-1)
+        n_prod = len(self.llms)
+        if flow_cu_exclude is None:
+            flow_cu_exclude = 80 if n_prod == 1 else 0
         s_fv = self._masked_stream(flow_cu_exclude) if flow_cu_exclude > 0 else torch.cuda.Stream(device=dev)
-        q: "queue.Queue" = queue.Queue(maxsize=2)
+        qs = [queue.Queue(maxsize=2) for _ in range(n_prod)]
         z = torch.zeros(1, 0, dtype=torch.int32)
 
-        def producer():
+        def producer(pi):
+            llm, q = self.llms[pi], qs[pi]
             try:
-                with torch.cuda.device(dev), torch.cuda.stream(s_llm):
-                    for bi, inputs in enumerate(batches):
+                with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev, priority=-1)):
+                    for bi in range(pi, len(batches), n_prod):
+                        inputs = batches[bi]
                         text = [d["text"].reshape(-1).tolist() for d in inputs]
                         ptext = [d.get("prompt_text", z).reshape(-1).tolist() for d in inputs]
                         pspeech = [d.get("llm_prompt_speech_token", z).reshape(-1).tolist() for d in inputs]
                         mn = min_len[bi] if min_len is not None else None
                         mx = max_len[bi] if max_len is not None else None
-                        out, out_n, _ = self.llm.generate(text, ptext, pspeech, min_len=mn, max_len=mx)
-                        n_tok = out_n.cpu().tolist()              # synchronises s_llm: the ids are complete
+                        out, out_n, _ = llm.generate(text, ptext, pspeech, min_len=mn, max_len=mx)
+                        n_tok = out_n.cpu().tolist()              # synchronises the LM stream: the ids are complete
                         q.put((inputs, out, n_tok))
-                q.put(None)
-            except BaseException as e:                             # surface in the consumer
+            except BaseException as e:                             # surfaces in the consumer
                 q.put(e)
 
-        t = th.Thread(target=producer, daemon=True)
+        threads = [th.Thread(target=producer, args=(i,), daemon=True) for i in range(n_prod)]
         with self.lock:
-            t.start()
+            for t in threads:
+                t.start()
             with torch.cuda.stream(s_fv):
-                while True:
-                    item = q.get()
-                    if item is None:
-                        break
+                for bi in range(len(batches)):
+                    item = qs[bi % n_prod].get()
                     if isinstance(item, BaseException):
                         raise item
                     inputs, out, n_tok = item
@@ -116,7 +123,8 @@ class CosyVoice3Model:
                     wav, samples = self._token2wav(inputs, out, n_tok, 1.0)
                     s_fv.synchronize()
                     yield (wav if keep_on_device else wav.cpu()), samples, [out[b, : n_tok[b]] for b in range(len(inputs))]
-            t.join()
+            for t in threads:
+                t.join()
 
     def _masked_stream(self, exclude: int):
         """A HIP stream whose kernels may not run on the first `exclude` CUs (cached per value)."""

@@ -38,14 +38,14 @@ def e2e_input(cfg, n_text, n_ptext, p_llm, p_flow):
     }, ctag
 
 
-def build(cfg, max_batch, p_flow_max):
+def build(cfg, max_batch, p_flow_max, n_llm=1):
     from fangyan_tts_amd.cli.model import CosyVoice3Model
     sd = [synth.state_dict_torch(m.manifest(), DEV, skip=("lm_head",)) for m in (cfg.llm, cfg.flow, cfg.hift)]
     noise = torch.from_numpy(synth.flow_rand_noise(2 * (p_flow_max + 20 * 8)))
     ri = torch.from_numpy(synth.hift_rand_ini())
     sn = torch.from_numpy(synth.hift_sine_noise(2 * 20 * 8 * 480))
     m = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, device=DEV, max_batch=max_batch, max_text=32, max_prompt_tokens=32, max_tokens=160,
-                        rand_noise=noise, rand_ini=ri, sine_noise=sn)
+                        rand_noise=noise, rand_ini=ri, sine_noise=sn, n_llm=n_llm)
     return m, sd, ri, sn
 
 
@@ -122,6 +122,21 @@ def test_pipeline_equals_batches(tiny):
     batches = [[ins[0]], [ins[1], ins[0]], [ins[1]]]
     ref = [m.tts_batch(b) for b in batches]
     got = list(m.tts_pipeline(batches))
+    assert len(got) == len(ref)
+    for (w, s, t), (w2, s2, t2) in zip(got, ref):
+        assert s == s2 and all(torch.equal(a, b) for a, b in zip(t, t2))
+        for b in range(len(s)):
+            assert maxerr(w[b, : s[b]], w2[b, : s2[b]]) < 1e-5
+
+
+def test_pipeline_two_lm_handles(tiny):
+    """Two LM handles decoding alternate batches concurrently (bench.py's default) change nothing in the results."""
+    m, cfg, sd, ri, sn = tiny
+    m2, _, _, _ = build(cfg, 4, 20, n_llm=2)
+    ins = [e2e_input(cfg, *c)[0] for c in CASES]
+    batches = [[ins[0]], [ins[1], ins[0]], [ins[1]], [ins[0], ins[1]], [ins[0]]]
+    ref = [m.tts_batch(b) for b in batches]
+    got = list(m2.tts_pipeline(batches, flow_cu_exclude=0))
     assert len(got) == len(ref)
     for (w, s, t), (w2, s2, t2) in zip(got, ref):
         assert s == s2 and all(torch.equal(a, b) for a, b in zip(t, t2))
