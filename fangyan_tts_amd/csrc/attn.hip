@@ -11,142 +11,148 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
 #define AT_D 64
-#define AT_PITCH 72          // bf16 elements per LDS row (64 + 8 pad)
+#define AT_KP 72             // bf16 elements per LDS row of the K tile (64 + 8 pad: conflict-free ds_read_b128 rows)
+#define AT_VP 96             // V tile pitch: 48 dwords, so the four rows of a transposed 4x16 block sit 16 banks apart
+#define AT_NW 2              // waves per workgroup, 32 queries each
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// The scores are computed TRANSPOSED, S^T = K Q^T (v_mfma_f32_32x32x16_bf16: A = K rows out of LDS, B = Q^T straight
+// from global memory), so a lane owns one query (its column) and 32 of the tile's 64 keys (its registers; the other
+// 32 are on lane^32): softmax statistics are per-lane scalars with one cross-half exchange, and the probabilities,
+// rounded to bf16 in place, ARE the B operand of O^T = V^T P^T -- no LDS round trip for P.  The k order of that second
+// product follows the accumulator's register order (key 16s + 8(j>>2) + 4h + (j&3) in element j of lane half h); the
+// A operand V^T is read to match, transposed by the LDS itself (ds_read_b64_tr_b16 on the row-major V tile).
 // qkv: bf16 [nseq*Tmax][3*H*64] as [q | k | v]; out: bf16 [nseq*Tmax][H*64]
-__global__ __launch_bounds__(256) void dit_attention_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                       const int* __restrict__ seq_len, int Tmax, int H, int chunk, float scale) {
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * AT_PITCH];
-    __shared__ __attribute__((aligned(16))) bf16_t Vt[64 * AT_PITCH];          // [d][key]
-    __shared__ __attribute__((aligned(16))) bf16_t Pw[4 * 16 * AT_PITCH];      // per wave [q][key]
+__global__ __launch_bounds__(AT_NW * 64) void dit_attention_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                              const int* __restrict__ seq_len, int Tmax, int H, int chunk, float scale_log2) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * AT_KP];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * AT_VP];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+    const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (AT_NW * 32);
     const int len = seq_len[s];
     if (q0 >= len) return;
     const int ld = 3 * H * AT_D;
     const bf16_t* base = qkv + (long)s * Tmax * ld;
-    const int g = lane >> 4, lc = lane & 15;
-    const int qrow = q0 + wid * 16 + lc;                     // the row whose Q fragment this lane holds
-    frag_ab qf[2];
+    const int lr = lane & 31, hf = lane >> 5;
+    const int qrow = q0 + wid * 32 + lr;                     // this lane's query
+    frag_ab qf[4];                                           // B[k = 16ks + 8hf + j][col = query]
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        if (qrow < len) qf[ks] = *reinterpret_cast<const frag_ab*>(base + (long)qrow * ld + h * AT_D + ks * 32 + g * 8);
-        else
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const frag_ab*>(base + (long)min(qrow, len - 1) * ld + h * AT_D + ks * 16 + hf * 8);
+    f32x16 o[2];                                             // O^T[d = 32dt + (r&3) + 8(r>>2) + 4hf][query]
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qf[ks][j] = (__bf16)0.f;
-    }
-    f32x4 o[4];
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int nd = 0; nd < 4; ++nd) o[nd] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float mrow[4], lrow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { mrow[r] = -1e30f; lrow[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
     // keys this block may need: everything (non-causal) or up to the end of the last query's chunk
     int kend = len;
-    if (chunk > 0) kend = min(len, ((min(q0 + 63, len - 1) / chunk) + 1) * chunk);
-    bf16_t* pw = Pw + wid * 16 * AT_PITCH;
+    if (chunk > 0) kend = min(len, ((min(q0 + AT_NW * 32 - 1, len - 1) / chunk) + 1) * chunk);
+    const int lim = chunk > 0 ? min(len, ((min(qrow, len - 1) / chunk) + 1) * chunk) : len;   // keys < lim are visible to this query
     // K/V tiles are fetched one tile ahead into registers: the loads of tile t+1 fly under the MFMAs of tile t
-    uint4 kreg[2], vreg[2];
+    constexpr int NLD = 512 / (AT_NW * 64);                  // 16-byte chunks of a 64 x 64 bf16 tile per thread
+    uint4 kreg[NLD], vreg[NLD];
     auto load_kv = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int idx = tid + i * 256, key = idx >> 3, dc = (idx & 7) * 8;
-            kreg[i] = make_uint4(0, 0, 0, 0);
-            vreg[i] = kreg[i];
-            if (k0 + key < len) {
-                const bf16_t* p = base + (long)(k0 + key) * ld + h * AT_D + dc;
-                kreg[i] = *reinterpret_cast<const uint4*>(p + H * AT_D);
-                vreg[i] = *reinterpret_cast<const uint4*>(p + 2 * H * AT_D);
-            }
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * (AT_NW * 64), key = idx >> 3, dc = (idx & 7) * 8;
+            const bool ok = k0 + key < len;
+            const bf16_t* p = base + (long)min(k0 + key, len - 1) * ld + h * AT_D + dc;
+            kreg[i] = *reinterpret_cast<const uint4*>(p + H * AT_D);
+            vreg[i] = *reinterpret_cast<const uint4*>(p + 2 * H * AT_D);
+            if (!ok) { kreg[i] = make_uint4(0, 0, 0, 0); vreg[i] = kreg[i]; }
         }
     };
+    // transposed V read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4-key x 16-d block and
+    // receives column (lane & 15) of its four keys
+    const int gi = lane >> 4, li = lane & 15;
+    const int v_off = (4 * hf + (li >> 2)) * AT_VP + 16 * (gi & 1) + 4 * (li & 3);
     load_kv(0);
     for (int k0 = 0; k0 < kend; k0 += 64) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int idx = tid + i * 256, key = idx >> 3, dc = (idx & 7) * 8;
-            *reinterpret_cast<uint4*>(Ks + key * AT_PITCH + dc) = kreg[i];
-            const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vreg[i]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) Vt[(dc + j) * AT_PITCH + key] = ve[j];
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * (AT_NW * 64), key = idx >> 3, dc = (idx & 7) * 8;
+            *reinterpret_cast<uint4*>(Ks + key * AT_KP + dc) = kreg[i];
+            *reinterpret_cast<uint4*>(Vs + key * AT_VP + dc) = vreg[i];
         }
         __syncthreads();
         if (k0 + 64 < kend) load_kv(k0 + 64);
-        // S = Q K^T for this wave's 16 rows x 64 keys: sc[nb][r] = S[row 4g+r][key 16nb+lc]
-        f32x4 sc[4];
+        // S^T: sc[kt][r] = score of key k0 + 32kt + (r&3) + 8(r>>2) + 4hf against this lane's query
+        f32x16 sc[2];
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-            sc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                frag_ab kf = *reinterpret_cast<const frag_ab*>(Ks + (nb * 16 + lc) * AT_PITCH + ks * 32 + g * 8);
-                sc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, sc[nb], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                frag_ab kf = *reinterpret_cast<const frag_ab*>(Ks + (kt * 32 + lr) * AT_KP + ks * 16 + hf * 8);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kt], 0, 0, 0);
             }
         }
-        float tmax[4];
+        float mx = -1e30f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qr = q0 + wid * 16 + 4 * g + r;
-            const int lim = chunk > 0 ? min(len, ((qr / chunk) + 1) * chunk) : len;
-            float mx = -1e30f;
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                const int key = k0 + nb * 16 + lc;
-                float v = key < lim ? sc[nb][r] * scale : -1e30f;
-                sc[nb][r] = v;
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                const float v = key < lim ? sc[kt][r] * scale_log2 : -1e30f;
+                sc[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - mnew);
+        float ps = 0.f;
+        frag_ab pf[2][2];                                    // P^T as the B operand: [kt][k-step s] = registers 8s .. 8s+7
 #pragma unroll
-            for (int of = 1; of < 16; of <<= 1) mx = fmaxf(mx, __shfl_xor(mx, of, 64));
-            tmax[r] = mx;
-        }
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float mnew = fmaxf(mrow[r], tmax[r]);
-            const float alpha = __expf(mrow[r] - mnew);
-            float ps = 0.f;
-#pragma unroll
-            for (int nb = 0; nb < 4; ++nb) {
-                float p = sc[nb][r] > -1e29f ? __expf(sc[nb][r] - mnew) : 0.f;
+            for (int r = 0; r < 16; ++r) {
+                const float p = sc[kt][r] > -1e29f ? exp2f(sc[kt][r] - mnew) : 0.f;
                 ps += p;
-                pw[(4 * g + r) * AT_PITCH + nb * 16 + lc] = f32_to_bf16(p);
+                pf[kt][r >> 3][r & 7] = (__bf16)p;
             }
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        m_run = mnew;
 #pragma unroll
-            for (int of = 1; of < 16; of <<= 1) ps += __shfl_xor(ps, of, 64);
-            lrow[r] = lrow[r] * alpha + ps;
-            mrow[r] = mnew;
+        for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int nd = 0; nd < 4; ++nd) o[nd][r] *= alpha;
-        }
-        // the wave reads back only its own P rows; LDS ops of one wave complete in order
-        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0)
-        __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        // O^T += V^T P^T
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            frag_ab pf = *reinterpret_cast<const frag_ab*>(pw + lc * AT_PITCH + ks * 32 + g * 8);
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int nd = 0; nd < 4; ++nd) {
-                frag_ab vf = *reinterpret_cast<const frag_ab*>(Vt + (nd * 16 + lc) * AT_PITCH + ks * 32 + g * 8);
-                o[nd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[nd], 0, 0, 0);
-            }
-        }
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const bf16_t* vb = Vs + (kt * 32 + st * 16) * AT_VP + dt * 32 + v_off;
+                    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb));
+                    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + 8 * AT_VP));
+                    bf16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(frag_ab, vv), pf[kt][st], o[dt], 0, 0, 0);
+                }
     }
+    if (qrow >= len) return;
+    const float inv = 1.f / l_run;
+    bf16_t* op = out + ((long)s * Tmax + qrow) * (H * AT_D) + h * AT_D;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qr = q0 + wid * 16 + 4 * g + r;
-        if (qr >= len) continue;
-        const float inv = 1.f / lrow[r];
-        bf16_t* op = out + ((long)s * Tmax + qr) * (H * AT_D) + h * AT_D;
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd) op[nd * 16 + lc] = f32_to_bf16(o[nd][r] * inv);
-    }
+        for (int rb = 0; rb < 4; ++rb) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(o[dt][rb * 4 + 0] * inv) | ((uint32_t)f32_to_bf16(o[dt][rb * 4 + 1] * inv) << 16);
+            pk.y = (uint32_t)f32_to_bf16(o[dt][rb * 4 + 2] * inv) | ((uint32_t)f32_to_bf16(o[dt][rb * 4 + 3] * inv) << 16);
+            *reinterpret_cast<uint2*>(op + dt * 32 + rb * 8 + hf * 4) = pk;
+        }
 }
 
 int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st) {
     FY_CHECK(qkv && out && seq_len && nseq >= 1 && Tmax >= 1 && H >= 1, FY_ERR_ARG, "dit_attention: bad arguments");
-    dim3 grid(cdiv(Tmax, 64), H, nseq);
-    hipLaunchKernelGGL(dit_attention_k, grid, dim3(256), 0, st, qkv, out, seq_len, Tmax, H, chunk, 0.125f);
+    dim3 grid(cdiv(Tmax, AT_NW * 32), H, nseq);
+    hipLaunchKernelGGL(dit_attention_k, grid, dim3(AT_NW * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, 0.125f * 1.4426950408889634f);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }

@@ -7,9 +7,23 @@
 // from hifigan/generator.py:110-117, 682-700.
 #include "conv.h"
 #include "runtime.h"
+#include <algorithm>
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
+#ifndef FY_ABL
+#define FY_ABL 0
+#endif
+#if FY_ABL == 9
+__device__ unsigned long long fy_dbg[8];
+void conv_dbg_read(unsigned long long* out, bool reset) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fy_dbg), sizeof(fy_dbg));
+    if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(fy_dbg), z, sizeof(z)); }
+}
+#define DBG_T(i) do { long long _n = clock64(); if (tid == 0) atomicAdd(&fy_dbg[i], (unsigned long long)(_n - _t)); _t = _n; } while (0)
+#else
+#define DBG_T(i)
+#endif
 
 __device__ __forceinline__ int floordiv(int a, int b) {   // b > 0
     return a >= 0 ? a / b : -((-a + b - 1) / b);
@@ -189,6 +203,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
     const int nrows = row_hi - row_lo + 1;
     const float* xb = d.x + (long)b * d.x_bs;
     char* lo_tile = smem + (size_t)nrows_max * MF_ROWB;
+#if FY_ABL == 9
+    long long _t = clock64();
+#endif
     const bool wave_live = n32_base < N32;          // whole wave beyond the group's channels: only helps staging
     const bool tile1_live = n32_base + 1 < N32;
 
@@ -205,6 +222,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
         const int ccn = min(MF_CC, Cin_gp - ci0);          // multiple of 16
         const int q4 = ccn / 4;
         __syncthreads();
+        DBG_T(0);
         // branch-free and unrolled: out-of-range rows / channels read a clamped address and are zeroed by a select,
         // and the activation kind is a compile-time constant of the loop body, so several loads stay in flight
         const int total = nrows * q4;
@@ -226,7 +244,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
                     const int row = row_lo + r, ci = ci0 + c4;
                     rr[u] = r; cc[u] = c4;
                     okk[u] = row >= 0 && row < n_in && ci < Cin_g;
+#if FY_ABL == 1
+                    vv[u] = make_float4(0.f, 0.f, 0.f, (float)idx);
+#else
                     vv[u] = *reinterpret_cast<const float4*>(xb + (long)min(max(row, 0), row_max) * d.x_ld + ci_base + min(ci, ci_max));
+#endif
                     aa[u] = make_float4(1.f, 1.f, 1.f, 1.f);
                     if (ACT == ACT_SNAKE) aa[u] = *reinterpret_cast<const float4*>(d.alpha + ci_base + min(ci, ci_max));
                 }
@@ -268,8 +290,10 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
         if (d.pre_act == ACT_SNAKE) stage(std::integral_constant<int, ACT_SNAKE>{});
         else if (d.pre_act == ACT_LEAKY) stage(std::integral_constant<int, ACT_LEAKY>{});
         else stage(std::integral_constant<int, ACT_NONE>{});
+        DBG_T(1);
         __syncthreads();
-        if (!wave_live) continue;
+        DBG_T(2);
+        if (wave_live) {
         const int c16_0 = ci0 / 16, nk = NK ? NK : ccn / 16;  // nk <= MF_CC/16 = 8
         constexpr int KMAX = NK ? NK : MF_CC / 16;
         const int t1off = tile1_live ? 512 : 0;               // a dead second tile re-reads the first: no branch
@@ -313,51 +337,94 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
         };
         frag_ab h0[KH][2], h1[KH][2];
         load_b(0, 0, h0);
+#if FY_ABL == 4
+        load_b(0, 1, h1);
+#endif
+#if FY_ABL != 2
         for (int t = 0; t < d.KW; ++t) {
+#if FY_ABL != 4
             load_b(t, 1, h1);
+#endif
             tap_half(t, 0, h0);
+#if FY_ABL != 4
             if (t + 1 < d.KW) load_b(t + 1, 0, h0);
+#endif
             tap_half(t, 1, h1);
         }
+#endif
+        }
     }
+    // epilogue through LDS: the accumulator layout (channel on the lane, positions in registers) would move 4 bytes
+    // per lane and store; each wave parks half of its tile (32 positions x 64 channels) in the input tile's LDS,
+    // reads it back position-major and moves 16 bytes per lane: residual / accumulate operands are requested as a
+    // batch before the first store.
+    DBG_T(3);
+    __syncthreads();                                         // every wave is done with the input tile
+    DBG_T(4);
     if (!wave_live) return;
-    // epilogue: flags are wave-uniform, so each variant is straight-line code; the residual / accumulate
-    // operands of a 16-row fragment are all requested before the first store
+#if FY_ABL == 3
+    if (acc[0][0][0] + acc[1][1][5] + acc[0][1][3] + acc[1][0][7] != 123.456f) return;
+#endif
+    constexpr int EP = 68;                                   // fp32 pitch of the parked half tile
+    float* et = reinterpret_cast<float*>(smem) + wid * 32 * EP;
     const float osc = d.out_scale;
     const int qoff = d.reflect1 ? 1 : 0;
     float* yb = d.y + (long)b * d.y_bs;
     const float* rb = d.add_resid ? d.resid + (long)b * d.r_bs : nullptr;
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const bool col_live = tile1_live || c4 < 32;
+    const int co = g * Cout_g + n32_base * 32 + (col_live ? c4 : 0);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + co);
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        if (ni == 1 && !tile1_live) break;
-        const int co = g * Cout_g + (n32_base + ni) * 32 + lr;
-        const float bv = d.bias ? d.bias[co] : 0.f;
+    for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int pbase = p0 + wpi * 64 + mi * 32 + 4 * kh;
-            float rv[16], ov[16];
+        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = pbase + (r & 3) + 8 * (r >> 2);
-                const long q = p + qoff;
-                rv[r] = (rb && p < n_out) ? rb[q * d.r_ld + co] : 0.f;
-                ov[r] = (d.accumulate && p < n_out) ? yb[q * d.y_ld + co] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) et[((r & 3) + 8 * (r >> 2) + 4 * kh) * EP + ni * 32 + lr] = acc[mi][ni][r];
+        __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): the wave reads back only its own half tile
+        __builtin_amdgcn_wave_barrier();
+        const int pbase = p0 + wpi * 64 + mi * 32 + rsub;
+        float4 rv[8], ov[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = pbase + (r & 3) + 8 * (r >> 2);
-                if (p >= n_out) continue;
-                float v = apply_post(acc[mi][ni][r] + bv, d.post_act, d.post_slope);
-                const long q = p + qoff;
-                yb[q * d.y_ld + co] = ov[r] + (v + rv[r]) * osc;
-                if (d.reflect1 && p == 1) {                  // ReflectionPad1d((1,0)): row 0 mirrors conv row 1
-                    float r0 = rb ? rb[co] : 0.f;
-                    float o0 = d.accumulate ? yb[co] : 0.f;
-                    yb[co] = o0 + (v + r0) * osc;
-                }
+        for (int it = 0; it < 8; ++it) { rv[it] = make_float4(0.f, 0.f, 0.f, 0.f); ov[it] = rv[it]; }
+        if (rb) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const long q = min(pbase + it * 4, n_out - 1) + qoff;
+                rv[it] = *reinterpret_cast<const float4*>(rb + q * d.r_ld + co);
             }
         }
+        if (d.accumulate) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const long q = min(pbase + it * 4, n_out - 1) + qoff;
+                ov[it] = *reinterpret_cast<const float4*>(yb + q * d.y_ld + co);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int p = pbase + it * 4;
+            float4 v = *reinterpret_cast<const float4*>(et + (it * 4 + rsub) * EP + c4);
+            v.x = apply_post(v.x + bv.x, d.post_act, d.post_slope); v.y = apply_post(v.y + bv.y, d.post_act, d.post_slope);
+            v.z = apply_post(v.z + bv.z, d.post_act, d.post_slope); v.w = apply_post(v.w + bv.w, d.post_act, d.post_slope);
+            if (p >= n_out || !col_live) continue;
+            float4 o;
+            o.x = fmaf(v.x + rv[it].x, osc, ov[it].x); o.y = fmaf(v.y + rv[it].y, osc, ov[it].y);
+            o.z = fmaf(v.z + rv[it].z, osc, ov[it].z); o.w = fmaf(v.w + rv[it].w, osc, ov[it].w);
+            *reinterpret_cast<float4*>(yb + (long)(p + qoff) * d.y_ld + co) = o;
+            if (d.reflect1 && p == 1) {                      // ReflectionPad1d((1,0)): row 0 mirrors conv row 1
+                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), o0 = r0;
+                if (rb) r0 = *reinterpret_cast<const float4*>(rb + co);
+                if (d.accumulate) o0 = *reinterpret_cast<const float4*>(yb + co);
+                o0.x = fmaf(v.x + r0.x, osc, o0.x); o0.y = fmaf(v.y + r0.y, osc, o0.y);
+                o0.z = fmaf(v.z + r0.z, osc, o0.z); o0.w = fmaf(v.w + r0.w, osc, o0.w);
+                *reinterpret_cast<float4*>(yb + co) = o0;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                     // the next half overwrites the parked tile
     }
+    DBG_T(5);
 }
 
 template <int WP, int WC, bool PR, int NK>
@@ -378,6 +445,7 @@ static int launch_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st) {
     int nrows_max = (TP - 1 + (d.KW - 1) * d.dil) / d.up + 3;
     const int Cin_gp = ((d.Cin / d.groups + 15) / 16) * 16;
     size_t lds = (size_t)nrows_max * mf_rowb(Cin_gp) * (PR ? 2 : 1);
+    lds = std::max(lds, (size_t)WP * WC * 32 * 68 * sizeof(float));     // the epilogue parks half tiles there
     FY_CHECK(lds <= 160 * 1024, FY_ERR_ARG, "conv1d_bf16_mfma: input tile needs %zu B of LDS", lds);
     ProfScope prof("conv_mfma", 2.0 * d.B * d.L_out * (double)d.Cout * (d.Cin / d.groups) * d.KW, st);
     // every staged chunk has the same number of k steps when Cin_gp <= 128 or Cin_gp is a multiple of 128
@@ -401,6 +469,9 @@ int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_
     FY_CHECK(Cout_g % 32 == 0 && Cin_g % 4 == 0 && d.x_ld % 4 == 0, FY_ERR_ARG,
              "conv1d_bf16_mfma: Cout/groups %% 32, Cin/groups %% 4 and the input pitch %% 4 must be 0");
     FY_CHECK(((uintptr_t)d.x & 15) == 0 && (d.x_bs % 4) == 0, FY_ERR_ARG, "conv1d_bf16_mfma: input must be 16-B aligned");
+    FY_CHECK(((uintptr_t)d.y & 15) == 0 && (d.y_bs % 4) == 0 && d.y_ld % 4 == 0, FY_ERR_ARG, "conv1d_bf16_mfma: output must be 16-B aligned");
+    FY_CHECK(!d.add_resid || (((uintptr_t)d.resid & 15) == 0 && (d.r_bs % 4) == 0 && d.r_ld % 4 == 0), FY_ERR_ARG,
+             "conv1d_bf16_mfma: residual must be 16-B aligned");
     if (Cout_g >= 128) {
         return precise ? launch_mfma<2, 2, true>(d, w, st) : launch_mfma<2, 2, false>(d, w, st);
     }
