@@ -5,7 +5,10 @@
 //   conv1d_bf16_mfma  : implicit GEMM on v_mfma_f32_32x32x16_bf16; the input tile
 //                       (+ causal halo) is activated once and staged in LDS as
 //                       bf16, the taps walk LDS rows, weights stream from L2 in
-//                       fragment order.  fp32 in HBM on both sides.
+//                       fragment order.  fp32 in HBM on both sides, or the bf16
+//                       activation streams x_act / y_act between the two convs of
+//                       a ResBlock iteration (same values the LDS staging would
+//                       have produced, half the bytes, no staging arithmetic).
 #pragma once
 #include "common.h"
 
@@ -26,6 +29,13 @@ struct ConvDesc {
     int accumulate;                       // y[q] += v*scale  instead of  y[q] = v*scale
     float out_scale;
     int reflect1;                         // ReflectionPad1d((1,0)) of the conv output: row p -> q = p+1, q=0 <- p=1
+    // bf16 activation streams of the MFMA kernel (conv1d_bf16_mfma only; both optional):
+    //   x_act : the input, ALREADY activated and rounded by its producer, addressed like x (x, pre_act are ignored)
+    //   y_act : snake(result; alpha_out) rounded to bf16, addressed like y -- what the consumer conv would have
+    //           staged from y; y itself may then be null when nobody else reads it
+    const bf16_t* x_act;
+    bf16_t* y_act;
+    const float* alpha_out;
 };
 
 // weights of one conv in both kernel layouts (either may be null)

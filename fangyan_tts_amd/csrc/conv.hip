@@ -179,7 +179,7 @@ static __host__ __device__ inline int mf_rowb(int cin_gp) { return (cin_gp < MF_
 // NK: 16-wide k steps per staged channel chunk when that is the same for every chunk of the launch (4, 6, 8);
 // 0 = decided at run time (odd channel counts of reduced-size models).  A compile-time NK and clamped addresses
 // keep the hot loops free of branches, so the compiler batches their loads instead of waiting on each one.
-template <int WAVES_P, int WAVES_C, bool PRECISE, int NK>
+template <int WAVES_P, int WAVES_C, bool PRECISE, int NK, bool INB>
 __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(ConvDesc d, const bf16_t* __restrict__ wp, int nrows_max) {
     constexpr int TP = WAVES_P * 64, TCO = WAVES_C * 64, NT = WAVES_P * WAVES_C * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];    // hi tile [nrows_max][MF_ROWB] (+ lo tile when PRECISE)
@@ -287,7 +287,34 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
                 }
             }
         };
-        if (d.pre_act == ACT_SNAKE) stage(std::integral_constant<int, ACT_SNAKE>{});
+        if (INB) {
+            // the producer already activated and rounded this operand: a straight copy, every load of the tile in
+            // flight at once (<= SBB 16-byte chunks per thread), zero rows selected in registers
+            constexpr int SBB = 12;
+            const int q8 = ccn / 8, total8 = nrows * q8;
+            const bool q8_pow2 = (q8 & (q8 - 1)) == 0;
+            const int q8_sh = 31 - __clz(q8);
+            const bf16_t* xa = d.x_act + (long)b * d.x_bs;
+            for (int base = tid; base < total8; base += NT * SBB) {
+                uint4 vv[SBB];
+                int off[SBB];
+#pragma unroll
+                for (int u = 0; u < SBB; ++u) {
+                    const int idx = min(base + u * NT, total8 - 1);
+                    const int r = q8_pow2 ? (idx >> q8_sh) : idx / q8;
+                    const int c8 = (idx - r * q8) * 8;
+                    const int row = row_lo + r;
+                    vv[u] = *reinterpret_cast<const uint4*>(xa + (long)min(max(row, 0), row_max) * d.x_ld + ci_base + ci0 + c8);
+                    off[u] = (row >= 0 && row < n_in) ? r * MF_ROWB + c8 * 2 : -1 - (r * MF_ROWB + c8 * 2);
+                }
+#pragma unroll
+                for (int u = 0; u < SBB; ++u) {
+                    if (base + u * NT >= total8) break;
+                    const bool ok = off[u] >= 0;
+                    *reinterpret_cast<uint4*>(smem + (ok ? off[u] : -1 - off[u])) = ok ? vv[u] : make_uint4(0, 0, 0, 0);
+                }
+            }
+        } else if (d.pre_act == ACT_SNAKE) stage(std::integral_constant<int, ACT_SNAKE>{});
         else if (d.pre_act == ACT_LEAKY) stage(std::integral_constant<int, ACT_LEAKY>{});
         else stage(std::integral_constant<int, ACT_NONE>{});
         DBG_T(1);
@@ -369,69 +396,88 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
     float* et = reinterpret_cast<float*>(smem) + wid * 32 * EP;
     const float osc = d.out_scale;
     const int qoff = d.reflect1 ? 1 : 0;
-    float* yb = d.y + (long)b * d.y_bs;
+    float* yb = d.y ? d.y + (long)b * d.y_bs : nullptr;
+    bf16_t* ya = d.y_act ? d.y_act + (long)b * d.y_bs : nullptr;
     const float* rb = d.add_resid ? d.resid + (long)b * d.r_bs : nullptr;
     const int c4 = (lane & 15) * 4, rsub = lane >> 4;
     const bool col_live = tile1_live || c4 < 32;
     const int co = g * Cout_g + n32_base * 32 + (col_live ? c4 : 0);
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), av = make_float4(1.f, 1.f, 1.f, 1.f);
     if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + co);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) et[((r & 3) + 8 * (r >> 2) + 4 * kh) * EP + ni * 32 + lr] = acc[mi][ni][r];
-        __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): the wave reads back only its own half tile
-        __builtin_amdgcn_wave_barrier();
-        const int pbase = p0 + wpi * 64 + mi * 32 + rsub;
-        float4 rv[8], ov[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) { rv[it] = make_float4(0.f, 0.f, 0.f, 0.f); ov[it] = rv[it]; }
-        if (rb) {
-#pragma unroll
+    if (ya) av = *reinterpret_cast<const float4*>(d.alpha_out + co);
+    // two instantiations: the plain one (no output activation, no reflect pad: every ResBlock conv) stays small --
+    // the generic one carries the transcendental code of every activation kind at each of its 64 elements
+    auto epilogue = [&](auto generic_tag) {
+        constexpr bool GENERIC = decltype(generic_tag)::value;
+    #pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+    #pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) et[((r & 3) + 8 * (r >> 2) + 4 * kh) * EP + ni * 32 + lr] = acc[mi][ni][r];
+            __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): the wave reads back only its own half tile
+            __builtin_amdgcn_wave_barrier();
+            const int pbase = p0 + wpi * 64 + mi * 32 + rsub;
+            float4 rv[8], ov[8];
+    #pragma unroll
+            for (int it = 0; it < 8; ++it) { rv[it] = make_float4(0.f, 0.f, 0.f, 0.f); ov[it] = rv[it]; }
+            if (rb) {
+    #pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const long q = min(pbase + it * 4, n_out - 1) + qoff;
+                    rv[it] = *reinterpret_cast<const float4*>(rb + q * d.r_ld + co);
+                }
+            }
+            if (d.accumulate && yb) {
+    #pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const long q = min(pbase + it * 4, n_out - 1) + qoff;
+                    ov[it] = *reinterpret_cast<const float4*>(yb + q * d.y_ld + co);
+                }
+            }
+    #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                const long q = min(pbase + it * 4, n_out - 1) + qoff;
-                rv[it] = *reinterpret_cast<const float4*>(rb + q * d.r_ld + co);
+                const int p = pbase + it * 4;
+                float4 v = *reinterpret_cast<const float4*>(et + (it * 4 + rsub) * EP + c4);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (GENERIC) {
+                    v.x = apply_post(v.x, d.post_act, d.post_slope); v.y = apply_post(v.y, d.post_act, d.post_slope);
+                    v.z = apply_post(v.z, d.post_act, d.post_slope); v.w = apply_post(v.w, d.post_act, d.post_slope);
+                }
+                if (p >= n_out || !col_live) continue;
+                float4 o;
+                o.x = fmaf(v.x + rv[it].x, osc, ov[it].x); o.y = fmaf(v.y + rv[it].y, osc, ov[it].y);
+                o.z = fmaf(v.z + rv[it].z, osc, ov[it].z); o.w = fmaf(v.w + rv[it].w, osc, ov[it].w);
+                if (yb) *reinterpret_cast<float4*>(yb + (long)(p + qoff) * d.y_ld + co) = o;
+                if (ya) {                                        // what the consumer conv would stage from this value
+                    o.x = snake_fast(o.x, av.x); o.y = snake_fast(o.y, av.y); o.z = snake_fast(o.z, av.z); o.w = snake_fast(o.w, av.w);
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
+                    *reinterpret_cast<uint2*>(ya + (long)(p + qoff) * d.y_ld + co) = pk;
+                }
+                if (GENERIC && mi == 0 && it == 0 && d.reflect1 && p == 1) {                      // ReflectionPad1d((1,0)): row 0 mirrors conv row 1
+                    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), o0 = r0;
+                    if (rb) r0 = *reinterpret_cast<const float4*>(rb + co);
+                    if (d.accumulate) o0 = *reinterpret_cast<const float4*>(yb + co);
+                    o0.x = fmaf(v.x + r0.x, osc, o0.x); o0.y = fmaf(v.y + r0.y, osc, o0.y);
+                    o0.z = fmaf(v.z + r0.z, osc, o0.z); o0.w = fmaf(v.w + r0.w, osc, o0.w);
+                    *reinterpret_cast<float4*>(yb + co) = o0;
+                }
             }
+            __builtin_amdgcn_wave_barrier();                     // the next half overwrites the parked tile
         }
-        if (d.accumulate) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const long q = min(pbase + it * 4, n_out - 1) + qoff;
-                ov[it] = *reinterpret_cast<const float4*>(yb + q * d.y_ld + co);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int p = pbase + it * 4;
-            float4 v = *reinterpret_cast<const float4*>(et + (it * 4 + rsub) * EP + c4);
-            v.x = apply_post(v.x + bv.x, d.post_act, d.post_slope); v.y = apply_post(v.y + bv.y, d.post_act, d.post_slope);
-            v.z = apply_post(v.z + bv.z, d.post_act, d.post_slope); v.w = apply_post(v.w + bv.w, d.post_act, d.post_slope);
-            if (p >= n_out || !col_live) continue;
-            float4 o;
-            o.x = fmaf(v.x + rv[it].x, osc, ov[it].x); o.y = fmaf(v.y + rv[it].y, osc, ov[it].y);
-            o.z = fmaf(v.z + rv[it].z, osc, ov[it].z); o.w = fmaf(v.w + rv[it].w, osc, ov[it].w);
-            *reinterpret_cast<float4*>(yb + (long)(p + qoff) * d.y_ld + co) = o;
-            if (d.reflect1 && p == 1) {                      // ReflectionPad1d((1,0)): row 0 mirrors conv row 1
-                float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), o0 = r0;
-                if (rb) r0 = *reinterpret_cast<const float4*>(rb + co);
-                if (d.accumulate) o0 = *reinterpret_cast<const float4*>(yb + co);
-                o0.x = fmaf(v.x + r0.x, osc, o0.x); o0.y = fmaf(v.y + r0.y, osc, o0.y);
-                o0.z = fmaf(v.z + r0.z, osc, o0.z); o0.w = fmaf(v.w + r0.w, osc, o0.w);
-                *reinterpret_cast<float4*>(yb + co) = o0;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                     // the next half overwrites the parked tile
-    }
+    };
+    if (d.post_act == ACT_NONE && !d.reflect1) epilogue(std::false_type{});
+    else epilogue(std::true_type{});
     DBG_T(5);
 }
 
-template <int WP, int WC, bool PR, int NK>
+template <int WP, int WC, bool PR, int NK, bool INB>
 static int launch_mfma2(const ConvDesc& d, const ConvW& w, int nrows_max, size_t lds, hipStream_t st) {
     int Cout_g = d.Cout / d.groups;
     dim3 grid(cdiv(d.L_out, WP * 64), d.groups * cdiv(Cout_g, WC * 64), d.B);
-    auto kern = conv1d_bf16_mfma_k<WP, WC, PR, NK>;
+    auto kern = conv1d_bf16_mfma_k<WP, WC, PR, NK, INB>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, grid, dim3(WP * WC * 64), lds, st, d, w.w_mfma, nrows_max);
@@ -439,7 +485,7 @@ static int launch_mfma2(const ConvDesc& d, const ConvW& w, int nrows_max, size_t
     return FY_OK;
 }
 
-template <int WP, int WC, bool PR>
+template <int WP, int WC, bool PR, bool INB>
 static int launch_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st) {
     constexpr int TP = WP * 64;
     int nrows_max = (TP - 1 + (d.KW - 1) * d.dil) / d.up + 3;
@@ -452,10 +498,10 @@ static int launch_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st) {
     int nk = 0;
     if (Cin_gp <= MF_CC) nk = Cin_gp / 16; else if (Cin_gp % MF_CC == 0) nk = MF_CC / 16;
     switch (nk) {
-        case 4: return launch_mfma2<WP, WC, PR, 4>(d, w, nrows_max, lds, st);
-        case 6: return launch_mfma2<WP, WC, PR, 6>(d, w, nrows_max, lds, st);
-        case 8: return launch_mfma2<WP, WC, PR, 8>(d, w, nrows_max, lds, st);
-        default: return launch_mfma2<WP, WC, PR, 0>(d, w, nrows_max, lds, st);
+        case 4: return launch_mfma2<WP, WC, PR, 4, INB>(d, w, nrows_max, lds, st);
+        case 6: return launch_mfma2<WP, WC, PR, 6, INB>(d, w, nrows_max, lds, st);
+        case 8: return launch_mfma2<WP, WC, PR, 8, INB>(d, w, nrows_max, lds, st);
+        default: return launch_mfma2<WP, WC, PR, 0, INB>(d, w, nrows_max, lds, st);
     }
 }
 
@@ -468,14 +514,26 @@ int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_
     int Cin_g = d.Cin / d.groups, Cout_g = d.Cout / d.groups;
     FY_CHECK(Cout_g % 32 == 0 && Cin_g % 4 == 0 && d.x_ld % 4 == 0, FY_ERR_ARG,
              "conv1d_bf16_mfma: Cout/groups %% 32, Cin/groups %% 4 and the input pitch %% 4 must be 0");
-    FY_CHECK(((uintptr_t)d.x & 15) == 0 && (d.x_bs % 4) == 0, FY_ERR_ARG, "conv1d_bf16_mfma: input must be 16-B aligned");
-    FY_CHECK(((uintptr_t)d.y & 15) == 0 && (d.y_bs % 4) == 0 && d.y_ld % 4 == 0, FY_ERR_ARG, "conv1d_bf16_mfma: output must be 16-B aligned");
+    FY_CHECK(d.y || d.y_act, FY_ERR_ARG, "conv1d_bf16_mfma: no output");
+    FY_CHECK(d.y_ld % 4 == 0 && (d.y_bs % 4) == 0, FY_ERR_ARG, "conv1d_bf16_mfma: output pitch must be a multiple of 4");
+    FY_CHECK(!d.y || ((uintptr_t)d.y & 15) == 0, FY_ERR_ARG, "conv1d_bf16_mfma: output must be 16-B aligned");
+    FY_CHECK(!d.y_act || (((uintptr_t)d.y_act & 7) == 0 && d.alpha_out && !d.reflect1), FY_ERR_ARG,
+             "conv1d_bf16_mfma: the bf16 output stream needs 8-B alignment, alpha_out and no reflect pad");
+    FY_CHECK(d.y || !(d.accumulate || d.reflect1), FY_ERR_ARG, "conv1d_bf16_mfma: accumulate / reflect need the fp32 output");
     FY_CHECK(!d.add_resid || (((uintptr_t)d.resid & 15) == 0 && (d.r_bs % 4) == 0 && d.r_ld % 4 == 0), FY_ERR_ARG,
              "conv1d_bf16_mfma: residual must be 16-B aligned");
-    if (Cout_g >= 128) {
-        return precise ? launch_mfma<2, 2, true>(d, w, st) : launch_mfma<2, 2, false>(d, w, st);
+    if (d.x_act) {
+        FY_CHECK(!precise, FY_ERR_ARG, "conv1d_bf16_mfma: the bf16 input stream has no split (precise) form");
+        FY_CHECK(((uintptr_t)d.x_act & 15) == 0 && d.x_bs % 8 == 0 && d.x_ld % 8 == 0 && Cin_g % 8 == 0 && d.up == 1, FY_ERR_ARG,
+                 "conv1d_bf16_mfma: the bf16 input stream needs 16-B aligned rows, Cin/groups %% 8 == 0 and no upsampling");
+        if (Cout_g >= 128) return launch_mfma<2, 2, false, true>(d, w, st);
+        return launch_mfma<4, 1, false, true>(d, w, st);
     }
-    return precise ? launch_mfma<4, 1, true>(d, w, st) : launch_mfma<4, 1, false>(d, w, st);
+    FY_CHECK(d.x && ((uintptr_t)d.x & 15) == 0 && (d.x_bs % 4) == 0, FY_ERR_ARG, "conv1d_bf16_mfma: input must be 16-B aligned");
+    if (Cout_g >= 128) {
+        return precise ? launch_mfma<2, 2, true, false>(d, w, st) : launch_mfma<2, 2, false, false>(d, w, st);
+    }
+    return precise ? launch_mfma<4, 1, true, false>(d, w, st) : launch_mfma<4, 1, false, false>(d, w, st);
 }
 
 // =============================================================================

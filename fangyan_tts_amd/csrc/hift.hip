@@ -391,10 +391,17 @@ static int hift_source(fy_hift* h, const float* f0, int B, int Fmax, const float
 
 // one ResBlock (generator.py:110-117): x_in -> out.  `work` holds the running x between iterations, `xt` the
 // inner activation.  final_dst/final_scale/final_acc: where the last iteration's x goes ((conv2 + x)*scale).
+// On the default (bf16 MFMA) path the operand of every conv but the first travels as a bf16 stream that its
+// producer's epilogue already activated (snake with the consumer's alpha) and rounded -- the very values the
+// consumer's LDS staging would have computed from the fp32 tensor -- so `xt` holds two bf16 streams instead of one
+// fp32 tensor: snake2_j(conv1_j(.)) for conv2_j, and snake1_{j+1}(x) for conv1_{j+1}.
 static int run_resblock(fy_hift* h, const HiftConvs::RB& rb, const float* x_in, float* work, float* xt, float* final_dst,
                         float final_scale, int final_acc, int B, int Lmax, const int* len, int C, uint32_t flags, hipStream_t st) {
     const fy_hift_config& c = h->cfg;
     const long bs = (long)Lmax * C;
+    const bool streams = !(flags & (FY_DIRECT | FY_PRECISE)) && rb.c1[0].w_mfma && C % 32 == 0;
+    bf16_t* a2 = reinterpret_cast<bf16_t*>(xt);
+    bf16_t* a1 = a2 + bs * B;
     for (int j = 0; j < N_DIL; ++j) {
         const float* cur = j == 0 ? x_in : work;
         ConvDesc d = base_desc(B);
@@ -402,6 +409,10 @@ static int run_resblock(fy_hift* h, const HiftConvs::RB& rb, const float* x_in, 
         d.y = xt; d.y_bs = bs; d.y_ld = C; d.L_out = Lmax; d.out_len = len;
         d.Cin = C; d.Cout = C; d.KW = rb.c1[j].KW; d.dil = c.rb_d[j]; d.pad_left = (d.KW - 1) * d.dil;
         d.pre_act = ACT_SNAKE; d.alpha = rb.a1[j]; d.bias = rb.c1[j].bias;
+        if (streams) {
+            if (j > 0) d.x_act = a1;
+            d.y = nullptr; d.y_act = a2; d.alpha_out = rb.a2[j];
+        }
         FY_TRY(run_conv(d, rb.c1[j], flags, st));
         ConvDesc e = base_desc(B);
         e.x = xt; e.x_bs = bs; e.x_ld = C; e.L_in = Lmax; e.in_len = len;
@@ -409,10 +420,12 @@ static int run_resblock(fy_hift* h, const HiftConvs::RB& rb, const float* x_in, 
         e.Cin = C; e.Cout = C; e.KW = rb.c2[j].KW; e.dil = 1; e.pad_left = e.KW - 1;
         e.pre_act = ACT_SNAKE; e.alpha = rb.a2[j]; e.bias = rb.c2[j].bias;
         e.add_resid = 1; e.resid = cur; e.r_bs = bs; e.r_ld = C;
+        if (streams) e.x_act = a2;
         if (j == N_DIL - 1) {
             e.y = final_dst; e.out_scale = final_scale; e.accumulate = final_acc;
         } else {
             e.y = work;
+            if (streams) { e.y_act = a1; e.alpha_out = rb.a1[j + 1]; }
         }
         e.y_bs = bs; e.y_ld = C;
         FY_TRY(run_conv(e, rb.c2[j], flags, st));

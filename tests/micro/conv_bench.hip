@@ -50,11 +50,17 @@ int main(int argc, char** argv) {
         d.y = y; d.y_bs = (long)s.L * s.C; d.y_ld = s.C; d.L_out = s.L;
         d.resid = r; d.r_bs = d.y_bs; d.r_ld = s.C; d.bias = w.bias; d.alpha = alpha;
         d.B = s.B; d.Cin = d.Cout = s.C; d.KW = s.KW; d.dil = s.dil; d.stride = 1; d.up = 1; d.pad_left = (s.KW - 1) * s.dil; d.groups = 1;
-        d.pre_act = argc > 1 ? atoi(argv[1]) : ACT_SNAKE; d.add_resid = s.resid; d.out_scale = 1.f;
+        d.pre_act = ACT_SNAKE; d.add_resid = s.resid; d.out_scale = 1.f;
+        const int streams = argc > 1 ? atoi(argv[1]) : 0;     // 1: bf16 streams as inside a ResBlock (conv1: bf16 in/out; conv2: bf16 in, fp32 RMW + bf16 out)
+        if (streams) {
+            d.x_act = reinterpret_cast<const bf16_t*>(x); d.alpha_out = alpha;
+            d.y_act = reinterpret_cast<bf16_t*>(y) + (size_t)s.B * s.L * s.C;
+            if (!s.resid) d.y = nullptr;
+        }
         float us = time_loop(st, 5, [&] { if (conv1d_bf16_mfma(d, w, false, st)) { printf("err %s\n", fy_last_error()); exit(1); } });
         double el = (double)s.B * s.L * s.C;
-        double gb = el * 4 * (2 + s.resid) / 1e9, tf = 2.0 * el * s.C * s.KW / 1e12;
-        printf("%-20s C %3d k %2d : %9.1f us  %6.2f TB/s (fp32 io)  %6.1f TFLOP/s\n", s.name, s.C, s.KW, us, gb / us * 1e3, tf / us * 1e6);
+        double gb = (streams ? el * (s.resid ? 2 + 4 + 4 + 2 : 4) : el * 4 * (2 + s.resid)) / 1e9, tf = 2.0 * el * s.C * s.KW / 1e12;
+        printf("%-20s C %3d k %2d : %9.1f us  %6.2f TB/s (moved)  %6.1f TFLOP/s\n", s.name, s.C, s.KW, us, gb / us * 1e3, tf / us * 1e6);
 #if FY_ABL == 9
         { unsigned long long t[8]; hipDeviceSynchronize(); conv_dbg_read(t, true);
           double tot = 0; for (int i = 0; i < 6; ++i) tot += t[i];
