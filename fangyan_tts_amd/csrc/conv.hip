@@ -188,7 +188,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
     const int b = blockIdx.z;
     const int Cin_g = d.Cin / d.groups, Cout_g = d.Cout / d.groups;
     const int Cin_gp = ((Cin_g + 15) / 16) * 16;
-    const int C16 = Cin_gp / 16, N32 = Cout_g / 32;
+    const int C16 = Cin_gp / 16, N32 = (Cout_g + 31) / 32;   // a ragged last 32-column tile has zero weights (groups == 1 only)
     const int MF_ROWB = mf_rowb(Cin_gp);
     const int tiles_per_g = (Cout_g + TCO - 1) / TCO;
     const int g = blockIdx.y / tiles_per_g;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
     bf16_t* ya = d.y_act ? d.y_act + (long)b * d.y_bs : nullptr;
     const float* rb = d.add_resid ? d.resid + (long)b * d.r_bs : nullptr;
     const int c4 = (lane & 15) * 4, rsub = lane >> 4;
-    const bool col_live = tile1_live || c4 < 32;
+    const bool col_live = (tile1_live || c4 < 32) && n32_base * 32 + c4 < ((Cout_g + 3) & ~3);
     const int co = g * Cout_g + n32_base * 32 + (col_live ? c4 : 0);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), av = make_float4(1.f, 1.f, 1.f, 1.f);
     if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + co);
@@ -498,6 +498,7 @@ static int launch_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st) {
     int nk = 0;
     if (Cin_gp <= MF_CC) nk = Cin_gp / 16; else if (Cin_gp % MF_CC == 0) nk = MF_CC / 16;
     switch (nk) {
+        case 2: return launch_mfma2<WP, WC, PR, 2, INB>(d, w, nrows_max, lds, st);
         case 4: return launch_mfma2<WP, WC, PR, 4, INB>(d, w, nrows_max, lds, st);
         case 6: return launch_mfma2<WP, WC, PR, 6, INB>(d, w, nrows_max, lds, st);
         case 8: return launch_mfma2<WP, WC, PR, 8, INB>(d, w, nrows_max, lds, st);
@@ -512,8 +513,8 @@ int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_
              w.Cin, w.Cout, w.KW, w.groups);
     FY_CHECK(d.stride == 1 && d.up >= 1 && d.dil >= 1 && d.B >= 1 && d.L_out >= 1, FY_ERR_ARG, "conv1d_bf16_mfma: bad geometry");
     int Cin_g = d.Cin / d.groups, Cout_g = d.Cout / d.groups;
-    FY_CHECK(Cout_g % 32 == 0 && Cin_g % 4 == 0 && d.x_ld % 4 == 0, FY_ERR_ARG,
-             "conv1d_bf16_mfma: Cout/groups %% 32, Cin/groups %% 4 and the input pitch %% 4 must be 0");
+    FY_CHECK((Cout_g % 32 == 0 || (d.groups == 1 && !d.y_act && d.y_ld >= ((Cout_g + 3) & ~3))) && Cin_g % 4 == 0 && d.x_ld % 4 == 0, FY_ERR_ARG,
+             "conv1d_bf16_mfma: Cout/groups %% 32 (or one group with an output pitch rounded up to 4), Cin/groups %% 4 and the input pitch %% 4 must be 0");
     FY_CHECK(d.y || d.y_act, FY_ERR_ARG, "conv1d_bf16_mfma: no output");
     FY_CHECK(d.y_ld % 4 == 0 && (d.y_bs % 4) == 0, FY_ERR_ARG, "conv1d_bf16_mfma: output pitch must be a multiple of 4");
     FY_CHECK(!d.y || ((uintptr_t)d.y & 15) == 0, FY_ERR_ARG, "conv1d_bf16_mfma: output must be 16-B aligned");
@@ -570,7 +571,7 @@ __global__ void pack_dir_k(const float* __restrict__ v, const float* __restrict_
 
 __global__ void pack_mfma_k(const float* __restrict__ v, const float* __restrict__ scale, bf16_t* __restrict__ out,
                             int Cout, int Cin_g, int KW, int groups) {
-    const int Cout_g = Cout / groups, Cin_gp = ((Cin_g + 15) / 16) * 16, C16 = Cin_gp / 16, N32 = Cout_g / 32;
+    const int Cout_g = Cout / groups, Cin_gp = ((Cin_g + 15) / 16) * 16, C16 = Cin_gp / 16, N32 = (Cout_g + 31) / 32;
     long n = (long)groups * KW * C16 * N32 * 512;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         int j = i & 7, l = (i >> 3) & 63;
@@ -581,7 +582,7 @@ __global__ void pack_mfma_k(const float* __restrict__ v, const float* __restrict
         int g = r / KW;
         int ci = c16 * 16 + (l >> 5) * 8 + j;
         int co = g * Cout_g + n32 * 32 + (l & 31);
-        float x = ci < Cin_g ? v[((long)co * Cin_g + ci) * KW + t] * scale[co] : 0.f;
+        float x = (ci < Cin_g && n32 * 32 + (l & 31) < Cout_g) ? v[((long)co * Cin_g + ci) * KW + t] * scale[co] : 0.f;
         out[i] = f32_to_bf16(x);
     }
 }
@@ -595,8 +596,10 @@ int conv_pack(ConvW& cw, const float* v, const float* g, const float* bias, int 
     float* scale = nullptr;
     HIP_TRY(hipMalloc(&scale, Cout * sizeof(float)));
     hipLaunchKernelGGL(wn_scale_k, dim3(Cout), dim3(256), 0, st, v, g, scale, Cin_g * KW);
-    if (bias) {
-        HIP_TRY(hipMalloc(&cw.bias, Cout * sizeof(float)));
+    if (bias) {                                              // padded: the MFMA epilogue reads whole 32-column tiles
+        const size_t nb = ((size_t)Cout + 31) / 32 * 32;
+        HIP_TRY(hipMalloc(&cw.bias, nb * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(cw.bias, 0, nb * sizeof(float), st));
         HIP_TRY(hipMemcpyAsync(cw.bias, bias, Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
     if (want_direct) {
@@ -606,8 +609,9 @@ int conv_pack(ConvW& cw, const float* v, const float* g, const float* bias, int 
                            cw.w_dir, Cout, Cin_g, KW, cw.cout_pad4());
     }
     if (want_mfma) {
-        FY_CHECK((Cout / groups) % 32 == 0, FY_ERR_ARG, "conv_pack: MFMA layout needs Cout/groups %% 32 == 0 (got %d)", Cout / groups);
-        long n = (long)groups * KW * (cw.cin_g_pad() / 16) * (Cout / groups / 32) * 512;
+        FY_CHECK((Cout / groups) % 32 == 0 || groups == 1, FY_ERR_ARG,
+                 "conv_pack: MFMA layout needs Cout/groups %% 32 == 0 when grouped (got %d)", Cout / groups);
+        long n = (long)groups * KW * (cw.cin_g_pad() / 16) * ((Cout / groups + 31) / 32) * 512;
         HIP_TRY(hipMalloc(&cw.w_mfma, n * sizeof(bf16_t)));
         hipLaunchKernelGGL(pack_mfma_k, dim3((int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, v, scale,
                            cw.w_mfma, Cout, Cin_g, KW, groups);

@@ -30,6 +30,10 @@ struct fy_hift {
     // activations (channels-last)
     float *mel_cl, *f0a, *f0b, *f0, *rad_phase, *source, *s_stft, *x_pre, *post, *spec;
     float *xs[N_UP], *x[N_UP], *r[N_UP], *xt[N_UP], *si[N_UP];
+    // bf16 'super-row' copies of s_stft for the strided source down-samplers (see stft16_k); null when not built
+    bf16_t* sb[N_UP] = {nullptr, nullptr, nullptr};
+    int sb_ld[N_UP] = {0, 0, 0};
+    ConvW sd_mfma[N_UP];
     int *lens;                                       // device: [6][max_batch] = F, L0, L1, L2conv, L2, S
     int B = 0, Fmax = 0;                             // of the last call (for taps)
     int L(int stage, int F) const {                  // rows of stage tensors for F frames
@@ -40,6 +44,8 @@ struct fy_hift {
     int C(int stage) const { return cfg.base >> (stage + 1); }
     ~fy_hift();
 };
+
+#define POST_LD 20     // fp32 pitch of the conv_post output rows (18 channels, rounded up for 16-byte row stores)
 
 extern "C" void fy_hift_default_config(fy_hift_config* c) {
     memset(c, 0, sizeof(*c));
@@ -60,7 +66,7 @@ static void source_down_shape(const fy_hift_config& c, int i, int* k, int* strid
 
 fy_hift::~fy_hift() {
     conv_free(w.conv_pre); conv_free(w.conv_post);
-    for (int i = 0; i < N_UP; ++i) { conv_free(w.ups[i]); conv_free(w.source_downs[i]); }
+    for (int i = 0; i < N_UP; ++i) { conv_free(w.ups[i]); conv_free(w.source_downs[i]); conv_free(sd_mfma[i]); }
     for (int i = 0; i < 5; ++i) conv_free(w.f0c[i]);
     auto free_rb = [](HiftConvs::RB& r) { for (int j = 0; j < N_DIL; ++j) { conv_free(r.c1[j]); conv_free(r.c2[j]); } };
     for (int i = 0; i < N_UP; ++i) free_rb(w.src_rb[i]);
@@ -68,12 +74,13 @@ fy_hift::~fy_hift() {
 }
 
 // ---- weight loading ---------------------------------------------------------------
-static int load_wn_conv(fy_hift* h, const Weights& W, const std::string& p, ConvW& cw, int Cout, int Cin, int KW, bool direct, bool mfma, hipStream_t st) {
+static int load_wn_conv(fy_hift* h, const Weights& W, const std::string& p, ConvW& cw, int Cout, int Cin, int KW, bool direct, bool mfma, hipStream_t st,
+                        bool pad_cout = false) {
     const float* g = W.get(p + ".parametrizations.weight.original0", {Cout, 1, 1});
     const float* v = W.get(p + ".parametrizations.weight.original1", {Cout, Cin, KW});
     const float* b = W.get(p + ".bias", {Cout});
     if (!g || !v || !b) return FY_ERR_WEIGHT;
-    if (mfma && (Cout % 32 != 0 || Cin % 4 != 0)) { mfma = false; direct = true; }
+    if (mfma && ((Cout % 32 != 0 && !pad_cout) || Cin % 4 != 0)) { mfma = false; direct = true; }
     return conv_pack(cw, v, g, b, Cout, Cin, KW, 1, direct, mfma, st);
 }
 
@@ -96,6 +103,26 @@ static int load_rb(fy_hift* h, const Weights& W, const std::string& p, HiftConvs
     return FY_OK;
 }
 
+// The strided source down-samplers (k = 2s, stride s, s-1 zero rows on the left; k = 1 when s = 1) as stride-1 convs:
+// output p reads s_stft rows s*p - s + 1 .. s*p + s, i.e. the two 'super-rows' S'[p], S'[p+1] where S'[j] holds rows
+// s*j - s + 1 .. s*j side by side (18 s channels, rounded up to `ld`).  A k = 2 (or 1) conv over Cin' = ld channels then
+// runs on the MFMA kernel from the bf16 copies stft16_k writes.  v' [Cout][ld][kk] <- v [Cout][18][k].
+__global__ void super_pack_k(const float* __restrict__ v, float* __restrict__ out, int Cout, int C, int k, int s, int ld, int kk) {
+    long n = (long)Cout * ld * kk;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        int t2 = i % kk;
+        long r = i / kk;
+        int cp = r % ld, co = r / ld;
+        int pos = cp / C, c = cp % C;
+        out[i] = pos < s ? v[((long)co * C + c) * k + t2 * s + pos] : 0.f;
+    }
+}
+
+static int super_ld(int C, int s) {
+    int n = C * s;
+    return n <= 128 ? (n + 31) / 32 * 32 : (n + 127) / 128 * 128;
+}
+
 extern "C" int fy_hift_create(fy_hift** out, const fy_hift_config* cfg, const fy_tensor* weights, int32_t n_weights,
                               int32_t max_batch, int32_t max_frames, void* stream) {
     FY_CHECK(out && max_batch >= 1 && max_frames >= 1, FY_ERR_ARG, "fy_hift_create: bad arguments");
@@ -113,7 +140,7 @@ extern "C" int fy_hift_create(fy_hift** out, const fy_hift_config* cfg, const fy
     if (c.n_fft != 16 || c.hop != 4) { fy_set_error("fy_hift_create: only n_fft 16 / hop 4 is built"); return fail(FY_ERR_ARG); }
 #define TRYC(e) do { int _r = (e); if (_r) return fail(_r); } while (0)
     TRYC(load_wn_conv(h, W, "conv_pre", h->w.conv_pre, c.base, c.mel, c.pre_look_right + 1, true, true, st));
-    TRYC(load_wn_conv(h, W, "conv_post", h->w.conv_post, c.n_fft + 2, h->C(N_UP - 1), 7, true, false, st));
+    TRYC(load_wn_conv(h, W, "conv_post", h->w.conv_post, c.n_fft + 2, h->C(N_UP - 1), 7, true, true, st, true));
     for (int i = 0; i < N_UP; ++i) {
         TRYC(load_wn_conv(h, W, "ups." + std::to_string(i), h->w.ups[i], h->C(i), c.base >> i, c.up_k[i], true, true, st));
         int k, s;
@@ -122,6 +149,16 @@ extern "C" int fy_hift_create(fy_hift** out, const fy_hift_config* cfg, const fy
         const float* b = W.get("source_downs." + std::to_string(i) + ".bias", {h->C(i)});
         if (!v || !b) return fail(FY_ERR_WEIGHT);
         TRYC(conv_pack(h->w.source_downs[i], v, nullptr, b, h->C(i), c.n_fft + 2, k, 1, true, false, st));
+        if (h->C(i) % 32 == 0) {
+            const int C18 = c.n_fft + 2, ld = super_ld(C18, s), kk = s == 1 ? 1 : 2;
+            float* vs = nullptr;
+            if (hipMalloc(&vs, (size_t)h->C(i) * ld * kk * sizeof(float)) != hipSuccess) { fy_set_error("fy_hift_create: hipMalloc failed"); return fail(FY_ERR_HIP); }
+            hipLaunchKernelGGL(super_pack_k, dim3(256), dim3(256), 0, st, v, vs, h->C(i), C18, k, s, ld, kk);
+            int rc2 = conv_pack(h->sd_mfma[i], vs, nullptr, b, h->C(i), ld, kk, 1, false, true, st);     // synchronises st
+            (void)hipFree(vs);
+            if (rc2) return fail(rc2);
+            h->sb_ld[i] = ld;
+        }
         TRYC(load_rb(h, W, "source_resblocks." + std::to_string(i), h->w.src_rb[i], h->C(i), c.src_rb_k[i], st));
         for (int j = 0; j < N_RB; ++j)
             TRYC(load_rb(h, W, "resblocks." + std::to_string(i * N_RB + j), h->w.rb[i * N_RB + j], h->C(i), c.rb_k[j], st));
@@ -151,7 +188,7 @@ extern "C" int fy_hift_create(fy_hift** out, const fy_hift_config* cfg, const fy
     const size_t T = F * h->stft_per_frame + 1;
     TRYC(h->pool.alloc(&h->s_stft, B * T * (c.n_fft + 2)));
     TRYC(h->pool.alloc(&h->x_pre, B * F * c.base));
-    TRYC(h->pool.alloc(&h->post, B * T * (c.n_fft + 2)));
+    TRYC(h->pool.alloc(&h->post, B * T * POST_LD));
     for (int i = 0; i < N_UP; ++i) {
         size_t n = B * (size_t)h->L(i, (int)F) * h->C(i);
         TRYC(h->pool.alloc(&h->x[i], n));
@@ -160,6 +197,8 @@ extern "C" int fy_hift_create(fy_hift** out, const fy_hift_config* cfg, const fy
         TRYC(h->pool.alloc(&h->xt[i], n));
         TRYC(h->pool.alloc(&h->si[i], n));
     }
+    for (int i = 0; i < N_UP; ++i)
+        if (h->sb_ld[i]) TRYC(h->pool.alloc(&h->sb[i], B * ((size_t)h->L(i, (int)F) + 1) * h->sb_ld[i]));
     TRYC(h->pool.alloc(&h->lens, 6 * B));
 #undef TRYC
     if (hipStreamSynchronize(st) != hipSuccess) { fy_set_error("fy_hift_create: stream sync failed"); return fail(FY_ERR_HIP); }
@@ -230,8 +269,16 @@ __global__ void source_k(const float* __restrict__ f0, const float* __restrict__
 
 __constant__ float c_cos16[16], c_sin16[16], c_hann16[16];
 
-// torch.stft(n_fft 16, hop 4, periodic hann, center + reflect), generator.py:491-497 -> (B, T, 18) = [re(9), im(9)]
-__global__ void stft16_k(const float* __restrict__ src, float* __restrict__ out, const int* __restrict__ frames, int Fmax, int up, int spf) {
+struct SuperRows {                                   // bf16 super-row copies of s_stft (null = not wanted)
+    bf16_t* p[N_UP]; int s[N_UP]; int ld[N_UP]; long bs[N_UP];
+};
+
+// torch.stft(n_fft 16, hop 4, periodic hann, center + reflect), generator.py:491-497 -> (B, T, 18) = [re(9), im(9)];
+// and the same rows, rounded to bf16, in the super-row layouts of the source down-samplers (super_pack_k): row tt lands in
+// S'[ceil(tt/s)] at position tt - s*ceil(tt/s) + s - 1; the thread that writes a super-row's last position also zeroes its
+// padding channels, and row 0's thread the s-1 positions before it (the conv's left zero padding).
+__global__ void stft16_k(const float* __restrict__ src, float* __restrict__ out, const int* __restrict__ frames, int Fmax, int up, int spf,
+                         SuperRows sr) {
     int b = blockIdx.y;
     int tt = blockIdx.x * 256 + threadIdx.x;
     int S = frames[b] * up;
@@ -247,6 +294,7 @@ __global__ void stft16_k(const float* __restrict__ src, float* __restrict__ out,
         fr[n] = s[i] * c_hann16[n];
     }
     float* o = out + ((long)b * (Fmax * spf + 1) + tt) * 18;
+    float val[18];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
         float re = 0.f, im = 0.f;
@@ -258,6 +306,27 @@ __global__ void stft16_k(const float* __restrict__ src, float* __restrict__ out,
         }
         o[k] = re;
         o[9 + k] = im;
+        val[k] = re; val[9 + k] = im;
+    }
+    uint32_t pk[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) pk[k] = (uint32_t)f32_to_bf16(val[2 * k]) | ((uint32_t)f32_to_bf16(val[2 * k + 1]) << 16);
+#pragma unroll
+    for (int i = 0; i < N_UP; ++i) {
+        if (!sr.p[i]) continue;
+        const int sd = sr.s[i], j = (tt + sd - 1) / sd, pos = tt - sd * j + sd - 1;
+        bf16_t* row = sr.p[i] + (long)b * sr.bs[i] + (long)j * sr.ld[i];
+        uint32_t* dst = reinterpret_cast<uint32_t*>(row + pos * 18);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dst[k] = pk[k];
+        if (pos == sd - 1) {
+            uint32_t* z = reinterpret_cast<uint32_t*>(row + sd * 18);
+            for (int k = 0; k < (sr.ld[i] - sd * 18) / 2; ++k) z[k] = 0u;
+        }
+        if (tt == 0) {
+            uint32_t* z = reinterpret_cast<uint32_t*>(row);
+            for (int k = 0; k < (sd - 1) * 9; ++k) z[k] = 0u;
+        }
     }
 }
 
@@ -269,7 +338,7 @@ __global__ void spec_k(const float* __restrict__ post, float* __restrict__ spec,
     if (i >= T * 9) return;
     long t = i / 9;
     int k = (int)(i % 9);
-    const float* p = post + ((long)b * (Fmax * spf + 1) + t) * 18;
+    const float* p = post + ((long)b * (Fmax * spf + 1) + t) * POST_LD;
     float mag = fminf(expf(p[k]), 100.f);
     float ph = sinf(p[9 + k]);
     float* o = spec + ((long)b * (Fmax * spf + 1) + t) * 18;
@@ -438,7 +507,15 @@ static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, 
     const int mb = h->max_batch;
     const int spf = h->stft_per_frame, up = h->up_total;
     const int Tmax = Fmax * spf + 1;
-    hipLaunchKernelGGL(stft16_k, dim3(cdiv(Tmax, 256), B), dim3(256), 0, st, h->source, h->s_stft, h->lens, Fmax, up, spf);
+    const bool streams = !(flags & (FY_DIRECT | FY_PRECISE));
+    SuperRows sr;
+    for (int i = 0; i < N_UP; ++i) {
+        int k, s;
+        source_down_shape(c, i, &k, &s);
+        sr.p[i] = streams ? h->sb[i] : nullptr; sr.s[i] = s; sr.ld[i] = h->sb_ld[i];
+        sr.bs[i] = ((long)h->L(i, Fmax) + 1) * h->sb_ld[i];
+    }
+    hipLaunchKernelGGL(stft16_k, dim3(cdiv(Tmax, 256), B), dim3(256), 0, st, h->source, h->s_stft, h->lens, Fmax, up, spf, sr);
     {   // conv_pre: k5, 4 frames of right look-ahead (generator.py:621-623, 675)
         ConvDesc d = base_desc(B);
         d.x = h->mel_cl; d.x_bs = (long)Fmax * c.mel; d.x_ld = c.mel; d.L_in = Fmax; d.in_len = h->lens;
@@ -462,7 +539,13 @@ static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, 
             d.x = h->s_stft; d.x_bs = (long)Tmax * 18; d.x_ld = 18; d.L_in = Tmax; d.in_len = h->lens + 4 * mb;
             d.y = h->r[i]; d.y_bs = bs; d.y_ld = C; d.L_out = Lmax; d.out_len = len;
             d.Cin = 18; d.Cout = C; d.KW = k; d.stride = s; d.pad_left = s == 1 ? 0 : s - 1; d.bias = h->w.source_downs[i].bias;
-            FY_TRY(conv1d_f32_direct(d, h->w.source_downs[i], st));
+            if (sr.p[i]) {       // stride-1 form over the bf16 super-rows (super_pack_k)
+                d.x_act = sr.p[i]; d.x_bs = sr.bs[i]; d.x_ld = sr.ld[i]; d.L_in = Lmax + 1; d.in_len = nullptr;
+                d.Cin = sr.ld[i]; d.KW = s == 1 ? 1 : 2; d.stride = 1; d.pad_left = 0;
+                FY_TRY(conv1d_bf16_mfma(d, h->sd_mfma[i], false, st));
+            } else {
+                FY_TRY(conv1d_f32_direct(d, h->w.source_downs[i], st));
+            }
             FY_TRY(run_resblock(h, h->w.src_rb[i], h->r[i], h->r[i], h->xt[i], h->si[i], 1.f, 0, B, Lmax, len, C, flags, st));
         }
         {   // x = ups[i](leaky_relu(x)) [reflect pad on the last stage] + si, generator.py:683-692
@@ -482,9 +565,9 @@ static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, 
     {   // conv_post on leaky_relu(x, 0.01), generator.py:702-703
         ConvDesc d = base_desc(B);
         d.x = xin; d.x_bs = (long)Lin_max * Cin; d.x_ld = Cin; d.L_in = Lin_max; d.in_len = len_in;
-        d.y = h->post; d.y_bs = (long)Tmax * 18; d.y_ld = 18; d.L_out = Tmax; d.out_len = len_in;
+        d.y = h->post; d.y_bs = (long)Tmax * POST_LD; d.y_ld = POST_LD; d.L_out = Tmax; d.out_len = len_in;
         d.Cin = Cin; d.Cout = 18; d.KW = 7; d.pad_left = 6; d.pre_act = ACT_LEAKY; d.pre_slope = 0.01f; d.bias = h->w.conv_post.bias;
-        FY_TRY(conv1d_f32_direct(d, h->w.conv_post, st));
+        FY_TRY(run_conv(d, h->w.conv_post, flags, st));
     }
     // the spectrum overwrites s_stft (no longer needed)
     hipLaunchKernelGGL(spec_k, dim3(cdiv(Tmax * 9, 256), B), dim3(256), 0, st, h->post, h->s_stft, h->lens, Fmax, spf);
@@ -549,7 +632,12 @@ extern "C" int fy_hift_tap(fy_hift* h, const char* name, float* dst, int64_t* ro
     if (n == "f0") { src = h->f0; *rows = F; *cols = 1; }
     else if (n == "source") { src = h->source; *rows = (int64_t)F * h->up_total; *cols = 1; }
     else if (n == "conv_pre") { src = h->x_pre; *rows = F; *cols = h->cfg.base; }
-    else if (n == "conv_post") { src = h->post; *rows = F * spf + 1; *cols = 18; }
+    else if (n == "conv_post") {
+        *rows = F * spf + 1; *cols = 18;
+        HIP_TRY(hipMemcpy2DAsync(dst, 18 * sizeof(float), h->post, POST_LD * sizeof(float), 18 * sizeof(float), (size_t)h->B * (*rows),
+                                 hipMemcpyDeviceToDevice, st));
+        return FY_OK;
+    }
     else if (n.size() == 5 && n.substr(0, 4) == "fuse" && n[4] >= '0' && n[4] < '0' + N_UP) {
         int i = n[4] - '0'; src = h->x[i]; *rows = h->L(i, F); *cols = h->C(i);
     } else if (n.size() == 6 && n.substr(0, 5) == "stage" && n[5] >= '0' && n[5] < '0' + N_UP) {
