@@ -2,6 +2,8 @@
 //   conv1d_f32_direct : exact fp32 VALU kernel, any shape (f0 predictor, source
 //                       down-samplers, conv_post, PreLookahead) and the on-GPU
 //                       cross-check of the MFMA kernel.
+//   conv1d_f32_mfma   : the same arithmetic as conv1d_f32_direct on the fp32 matrix
+//                       instruction (f0 predictor).
 //   conv1d_bf16_mfma  : implicit GEMM on v_mfma_f32_32x32x16_bf16; the input tile
 //                       (+ causal halo) is activated once and staged in LDS as
 //                       bf16, the taps walk LDS rows, weights stream from L2 in
@@ -52,7 +54,11 @@ struct ConvW {
 // w = g * v / ||v|| per output channel (torch._weight_norm, dim 0)
 int conv_pack(ConvW& cw, const float* v, const float* g, const float* bias, int Cout, int Cin, int KW, int groups,
               bool want_direct, bool want_mfma, hipStream_t st);
+// nearest-repeat x`up` + causal conv as a stride-1 conv with up*Cout output channels on the un-repeated input (MFMA layout only)
+int conv_pack_polyphase(ConvW& cw, const float* v, const float* g, const float* bias, int Cout, int Cin, int KW, int up, hipStream_t st);
 void conv_free(ConvW& cw);
 
 int conv1d_f32_direct(const ConvDesc& d, const ConvW& w, hipStream_t st);
 int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_t st);
+// exact fp32 on v_mfma_f32_32x32x2_f32 (w.w_dir layout); stride 1, one group, optional ELU
+int conv1d_f32_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st);

@@ -538,6 +538,129 @@ int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_
 }
 
 // =============================================================================
+// fp32 MFMA implicit-GEMM kernel (v_mfma_f32_32x32x2_f32): exact fp32 products and sums on the matrix cores, for the
+// layers that must stay fp32 (the f0 predictor: its output is integrated into the harmonic source's phase).
+//   block = 2 x 2 waves, each a 64-position x 64-channel tile; the input tile (32 channels at a time) sits in LDS
+//   as fp32, weights ([KW][Cin][Cout_pad] fp32, the direct kernel's layout) stream from L2 one tap ahead.
+//   stride 1, no up-sampling, one group.
+// =============================================================================
+#define FM_TP 128
+#define FM_TC 128
+#define FM_CC 32
+#define FM_PITCH 33
+
+template <int POST>
+__global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvDesc d, const float* __restrict__ w, int cout_pad) {
+    extern __shared__ __attribute__((aligned(16))) float fxs[];      // [FM_TP + (KW-1) dil][FM_PITCH]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wpi = wid >> 1, wci = wid & 1, lr = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.z, p0 = blockIdx.x * FM_TP, co0 = blockIdx.y * FM_TC + wci * 64;
+    const int n_out = d.out_len ? d.out_len[b] : d.L_out;
+    if (p0 >= n_out) return;
+    const int n_in = d.in_len ? d.in_len[b] : d.L_in;
+    const int row_lo = p0 - d.pad_left, nrows = FM_TP + (d.KW - 1) * d.dil;
+    const float* xb = d.x + (long)b * d.x_bs;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const int cob[2] = {min(co0 + lr, d.Cout - 1), min(co0 + 32 + lr, d.Cout - 1)};
+    for (int ci0 = 0; ci0 < d.Cin; ci0 += FM_CC) {
+        __syncthreads();
+        {   // clamped addresses + selects: the loads of a batch are all in flight before the first LDS write
+            constexpr int SB = 5;
+            const int total = nrows * (FM_CC / 4), row_max = max(n_in - 1, 0), ci_max = max(d.Cin - 4, 0);
+            for (int base = tid; base < total; base += 256 * SB) {
+                float4 vv[SB];
+                int off[SB];
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int idx = min(base + u * 256, total - 1);
+                    const int r = idx >> 3, c4 = (idx & 7) * 4, row = row_lo + r, ci = ci0 + c4;
+                    vv[u] = *reinterpret_cast<const float4*>(xb + (long)min(max(row, 0), row_max) * d.x_ld + min(ci, ci_max));
+                    off[u] = (row >= 0 && row < n_in && ci < d.Cin) ? r * FM_PITCH + c4 : -1 - (r * FM_PITCH + c4);
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    if (base + u * 256 >= total) break;
+                    const bool ok = off[u] >= 0;
+                    float* dst = fxs + (ok ? off[u] : -1 - off[u]);
+                    dst[0] = ok ? apply_pre(vv[u].x, d.pre_act, d.pre_slope, 0.f) : 0.f;
+                    dst[1] = ok ? apply_pre(vv[u].y, d.pre_act, d.pre_slope, 0.f) : 0.f;
+                    dst[2] = ok ? apply_pre(vv[u].z, d.pre_act, d.pre_slope, 0.f) : 0.f;
+                    dst[3] = ok ? apply_pre(vv[u].w, d.pre_act, d.pre_slope, 0.f) : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        float b0[FM_CC / 2][2], b1[FM_CC / 2][2];
+        auto load_w = [&](int t, float (&bb)[FM_CC / 2][2]) {
+#pragma unroll
+            for (int kk = 0; kk < FM_CC / 2; ++kk) {
+                const int ci = ci0 + 2 * kk + kh;
+                const float* wr = w + ((long)t * d.Cin + min(ci, d.Cin - 1)) * cout_pad;
+                // no guards: channels past Cin meet zero activations in LDS, columns past Cout are never stored
+                bb[kk][0] = wr[cob[0]];
+                bb[kk][1] = wr[cob[1]];
+            }
+        };
+        auto tap = [&](int t, const float (&bb)[FM_CC / 2][2]) {
+            const float* x0 = fxs + (wpi * 64 + lr + t * d.dil) * FM_PITCH + kh;
+#pragma unroll
+            for (int kk = 0; kk < FM_CC / 2; ++kk) {
+                const float a0 = x0[2 * kk], a1 = x0[32 * FM_PITCH + 2 * kk];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb[kk][0], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bb[kk][1], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb[kk][0], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bb[kk][1], acc[1][1], 0, 0, 0);
+            }
+        };
+        load_w(0, b0);
+        for (int t = 0; t < d.KW; t += 2) {
+            load_w(min(t + 1, d.KW - 1), b1);
+            tap(t, b0);
+            load_w(min(t + 2, d.KW - 1), b0);
+            if (t + 1 < d.KW) tap(t + 1, b1);
+        }
+    }
+    float* yb = d.y + (long)b * d.y_bs;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int co = co0 + ni * 32 + lr;
+        if (co >= d.Cout) continue;
+        const float bv = d.bias ? d.bias[co] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = p0 + wpi * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (p >= n_out) continue;
+                float v = acc[mi][ni][r] + bv;
+                if (POST == ACT_ELU) v = act_elu(v);
+                yb[(long)p * d.y_ld + co] = v;
+            }
+    }
+}
+
+int conv1d_f32_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st) {
+    FY_CHECK(w.w_dir != nullptr, FY_ERR_STATE, "conv1d_f32_mfma: weights not packed in the fp32 layout");
+    FY_CHECK(d.Cin == w.Cin && d.Cout == w.Cout && d.KW == w.KW && d.groups == 1 && w.groups == 1, FY_ERR_ARG, "conv1d_f32_mfma: descriptor != weights");
+    FY_CHECK(d.stride == 1 && d.up == 1 && d.dil >= 1 && d.B >= 1 && d.L_out >= 1 && !d.add_resid && !d.accumulate && !d.reflect1 &&
+             d.pre_act != ACT_SNAKE && (d.post_act == ACT_NONE || d.post_act == ACT_ELU) && d.Cin % 4 == 0 && d.x_ld % 4 == 0 && d.x_bs % 4 == 0 &&
+             ((uintptr_t)d.x & 15) == 0, FY_ERR_ARG, "conv1d_f32_mfma: unsupported fusion / geometry / alignment");
+    const size_t lds = (size_t)(FM_TP + (d.KW - 1) * d.dil) * FM_PITCH * sizeof(float);
+    FY_CHECK(lds <= 64 * 1024, FY_ERR_ARG, "conv1d_f32_mfma: input tile needs %zu B of LDS", lds);
+    dim3 grid(cdiv(d.L_out, FM_TP), cdiv(d.Cout, FM_TC), d.B);
+    if (d.post_act == ACT_ELU) hipLaunchKernelGGL(conv1d_f32_mfma_k<ACT_ELU>, grid, dim3(256), lds, st, d, w.w_dir, w.cout_pad4());
+    else hipLaunchKernelGGL(conv1d_f32_mfma_k<ACT_NONE>, grid, dim3(256), lds, st, d, w.w_dir, w.cout_pad4());
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+// =============================================================================
 // weight packing (load time)
 // =============================================================================
 __global__ void wn_scale_k(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ scale, int per_co) {
@@ -616,6 +739,58 @@ int conv_pack(ConvW& cw, const float* v, const float* g, const float* bias, int 
         hipLaunchKernelGGL(pack_mfma_k, dim3((int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, v, scale,
                            cw.w_mfma, Cout, Cin_g, KW, groups);
     }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipFree(scale));
+    return FY_OK;
+}
+
+// Nearest-repeat up-sampling (x u) followed by a causal k-tap conv, as ONE stride-1 conv on the un-repeated input
+// with u*Cout output channels: output row u n + phi reads repeated rows u n + phi + t - (k-1), i.e. input rows
+// n + floor((phi + t - k + 1) / u) -- only K' = ceil((k-1)/u) + 1 distinct ones -- so the taps that land on one
+// input row are summed beforehand: W'[phi Cout + co][ci][t'] = sum_{t : floor((phi+t-k+1)/u) = t'-(K'-1)} W[co][ci][t].
+// The result rows [n][phi Cout + co] ARE the channels-last up-sampled tensor [u n + phi][co].  k/K' fewer MFMAs.
+__global__ void pack_mfma_poly_k(const float* __restrict__ v, const float* __restrict__ scale, bf16_t* __restrict__ out,
+                                 int Cout, int Cin, int KW, int up, int K2) {
+    const int Cout2 = Cout * up, Cin_p = ((Cin + 15) / 16) * 16, C16 = Cin_p / 16, N32 = (Cout2 + 31) / 32;
+    long n = (long)K2 * C16 * N32 * 512;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        int j = i & 7, l = (i >> 3) & 63;
+        long r = i >> 9;
+        int n32 = r % N32; r /= N32;
+        int c16 = r % C16;
+        int t2 = r / C16;
+        int ci = c16 * 16 + (l >> 5) * 8 + j;
+        int co2 = n32 * 32 + (l & 31);
+        float x = 0.f;
+        if (ci < Cin && co2 < Cout2) {
+            const int phi = co2 / Cout, co = co2 % Cout, want = t2 - (K2 - 1);
+            for (int t = 0; t < KW; ++t) {
+                const int a = phi + t - KW + 1;
+                const int fl = a >= 0 ? a / up : -((-a + up - 1) / up);
+                if (fl == want) x += v[((long)co * Cin + ci) * KW + t] * scale[co];
+            }
+        }
+        out[i] = f32_to_bf16(x);
+    }
+}
+
+int conv_pack_polyphase(ConvW& cw, const float* v, const float* g, const float* bias, int Cout, int Cin, int KW, int up, hipStream_t st) {
+    FY_CHECK(Cout > 0 && Cin > 0 && KW > 0 && up > 1 && (Cout * up) % 32 == 0, FY_ERR_ARG, "conv_pack_polyphase: bad shape (%d,%d,%d,x%d)", Cout, Cin, KW, up);
+    const int K2 = (KW - 1 + up - 1) / up + 1, Cout2 = Cout * up;
+    cw.Cin = Cin; cw.Cout = Cout2; cw.KW = K2; cw.groups = 1;
+    float* scale = nullptr;
+    HIP_TRY(hipMalloc(&scale, Cout * sizeof(float)));
+    hipLaunchKernelGGL(wn_scale_k, dim3(Cout), dim3(256), 0, st, v, g, scale, Cin * KW);
+    if (bias) {
+        HIP_TRY(hipMalloc(&cw.bias, (size_t)Cout2 * sizeof(float)));
+        for (int p = 0; p < up; ++p)
+            HIP_TRY(hipMemcpyAsync(cw.bias + (size_t)p * Cout, bias, Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    long n = (long)K2 * (cw.cin_g_pad() / 16) * (Cout2 / 32) * 512;
+    HIP_TRY(hipMalloc(&cw.w_mfma, n * sizeof(bf16_t)));
+    hipLaunchKernelGGL(pack_mfma_poly_k, dim3((int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, st, v, scale, cw.w_mfma,
+                       Cout, Cin, KW, up, K2);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipFree(scale));

@@ -34,6 +34,7 @@ struct fy_hift {
     bf16_t* sb[N_UP] = {nullptr, nullptr, nullptr};
     int sb_ld[N_UP] = {0, 0, 0};
     ConvW sd_mfma[N_UP];
+    ConvW ups_poly[N_UP];                            // ups[i] in polyphase form (conv_pack_polyphase)
     int *lens;                                       // device: [6][max_batch] = F, L0, L1, L2conv, L2, S
     int B = 0, Fmax = 0;                             // of the last call (for taps)
     int L(int stage, int F) const {                  // rows of stage tensors for F frames
@@ -66,7 +67,7 @@ static void source_down_shape(const fy_hift_config& c, int i, int* k, int* strid
 
 fy_hift::~fy_hift() {
     conv_free(w.conv_pre); conv_free(w.conv_post);
-    for (int i = 0; i < N_UP; ++i) { conv_free(w.ups[i]); conv_free(w.source_downs[i]); conv_free(sd_mfma[i]); }
+    for (int i = 0; i < N_UP; ++i) { conv_free(w.ups[i]); conv_free(w.source_downs[i]); conv_free(sd_mfma[i]); conv_free(ups_poly[i]); }
     for (int i = 0; i < 5; ++i) conv_free(w.f0c[i]);
     auto free_rb = [](HiftConvs::RB& r) { for (int j = 0; j < N_DIL; ++j) { conv_free(r.c1[j]); conv_free(r.c2[j]); } };
     for (int i = 0; i < N_UP; ++i) free_rb(w.src_rb[i]);
@@ -143,6 +144,12 @@ extern "C" int fy_hift_create(fy_hift** out, const fy_hift_config* cfg, const fy
     TRYC(load_wn_conv(h, W, "conv_post", h->w.conv_post, c.n_fft + 2, h->C(N_UP - 1), 7, true, true, st, true));
     for (int i = 0; i < N_UP; ++i) {
         TRYC(load_wn_conv(h, W, "ups." + std::to_string(i), h->w.ups[i], h->C(i), c.base >> i, c.up_k[i], true, true, st));
+        if ((h->C(i) * c.ups[i]) % 32 == 0 && h->C(i) % 4 == 0 && (c.base >> i) % 4 == 0 && c.ups[i] > 1) {
+            const std::string p = "ups." + std::to_string(i);
+            TRYC(conv_pack_polyphase(h->ups_poly[i], W.get(p + ".parametrizations.weight.original1", {h->C(i), c.base >> i, c.up_k[i]}),
+                                     W.get(p + ".parametrizations.weight.original0", {h->C(i), 1, 1}), W.get(p + ".bias", {h->C(i)}),
+                                     h->C(i), c.base >> i, c.up_k[i], c.ups[i], st));
+        }
         int k, s;
         source_down_shape(c, i, &k, &s);
         const float* v = W.get("source_downs." + std::to_string(i) + ".weight", {h->C(i), c.n_fft + 2, k});
@@ -438,7 +445,7 @@ static int hift_f0(fy_hift* h, int B, int Fmax, hipStream_t st) {
         d.Cin = i == 0 ? c.mel : c.f0_ch; d.Cout = c.f0_ch; d.KW = h->w.f0c[i].KW;
         d.pad_left = i == 0 ? 0 : (d.KW - 1);
         d.bias = h->w.f0c[i].bias; d.post_act = ACT_ELU;
-        FY_TRY(conv1d_f32_direct(d, h->w.f0c[i], st));
+        FY_TRY(conv1d_f32_mfma(d, h->w.f0c[i], st));
         in = bufs[i & 1]; in_ld = c.f0_ch;
     }
     hipLaunchKernelGGL(f0_classifier_k, dim3(cdiv(Fmax, 4), B), dim3(256), 0, st, in, h->cls_w, h->cls_b, h->f0, lF, Fmax, c.f0_ch);
@@ -502,6 +509,15 @@ static int run_resblock(fy_hift* h, const HiftConvs::RB& rb, const float* x_in, 
     return FY_OK;
 }
 
+// ReflectionPad1d((1,0)) after the polyphase up-conv wrote rows 1..: row 0 = conv row 1 + si[0] = y[2] - si[2] + si[0]
+__global__ void reflect_row0_k(float* __restrict__ y, const float* __restrict__ si, long bs, int C) {
+    int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float* yb = y + (long)b * bs;
+    const float* sb = si + (long)b * bs;
+    yb[c] = yb[2 * C + c] - sb[2 * C + c] + sb[c];
+}
+
 static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, hipStream_t st) {
     const fy_hift_config& c = h->cfg;
     const int mb = h->max_batch;
@@ -556,7 +572,20 @@ static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, 
             d.pre_act = ACT_LEAKY; d.pre_slope = c.lrelu; d.bias = h->w.ups[i].bias;
             d.add_resid = 1; d.resid = h->si[i]; d.r_bs = bs; d.r_ld = C;
             d.reflect1 = i == N_UP - 1;
-            FY_TRY(run_conv(d, h->w.ups[i], flags, st));
+            if (streams && h->ups_poly[i].w_mfma) {
+                // polyphase form: rows [n][phi C + co] of a stride-1 conv over the un-repeated input are rows u n + phi
+                const int u = c.ups[i], off = d.reflect1 ? C : 0;
+                d.up = 1; d.KW = h->ups_poly[i].KW; d.pad_left = d.KW - 1; d.Cout = C * u; d.bias = h->ups_poly[i].bias;
+                d.L_out = Lin_max; d.out_len = len_in;
+                d.y = h->x[i] + off; d.y_ld = C * u; d.resid = h->si[i] + off; d.r_ld = C * u; d.reflect1 = 0;
+                FY_TRY(conv1d_bf16_mfma(d, h->ups_poly[i], false, st));
+                if (off) {
+                    hipLaunchKernelGGL(reflect_row0_k, dim3(cdiv(C, 256), B), dim3(256), 0, st, h->x[i], h->si[i], bs, C);
+                    HIP_TRY(hipGetLastError());
+                }
+            } else {
+                FY_TRY(run_conv(d, h->w.ups[i], flags, st));
+            }
         }
         for (int j = 0; j < N_RB; ++j)   // x = mean_j resblocks[3i+j](x), generator.py:694-700
             FY_TRY(run_resblock(h, h->w.rb[i * N_RB + j], h->x[i], h->r[i], h->xt[i], h->xs[i], 1.f / N_RB, j > 0, B, Lmax, len, C, flags, st));
