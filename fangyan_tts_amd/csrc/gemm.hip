@@ -1,11 +1,12 @@
 // See gemm.h.
 #include "gemm.h"
 #include "runtime.h"
+#include <algorithm>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
 #define GM_BM 128
-int gemm_tile_override = 0;        // 0 auto, 128 or 256: forces the M tile (microbenchmarks)
+int gemm_tile_override = 0;        // 0 auto; 128 / 64 force the register-staged kernel with that M tile (microbenchmarks)
 #define GM_BN 128
 #define GM_BK 64
 #define GM_PITCH 72          // bf16 elements per LDS row: 64 + 8 pad (144 B: 16-B aligned, spreads ds_read_b128 over banks)
@@ -21,6 +22,65 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
     }
     hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+// Epilogue shared by the GEMM kernels, through LDS: the accumulator layout (column on the lane, rows in registers)
+// would store 2-4 bytes per lane; each wave instead parks its 64x64 tile in LDS (the operand buffers are free by now)
+// and reads it back row-wise, so every lane moves 4 consecutive columns: 16 wide stores per lane instead of 64 narrow ones.
+template <int EPI>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], bf16_t* gm_smem, const GemmEpi& e, int M, int N, int m0, int n0,
+                                              int wm, int wn, int wid, int lane) {
+    const int lr = lane & 31, kh = lane >> 5;
+    constexpr int EP = 68;                                   // fp32 pitch of the per-wave tile
+    float* et = reinterpret_cast<float*>(gm_smem) + wid * 64 * EP;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) et[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * EP + ni * 32 + lr] = acc[mi][ni][r];
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the wave reads back only its own tile
+    __builtin_amdgcn_wave_barrier();
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int n = n0 + wn * 64 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gv = bv;
+    if (n < N) {                                             // N % 4 == 0 is checked on the host
+        if (e.bias) bv = *reinterpret_cast<const float4*>(e.bias + n);
+        if (EPI == 3) gv = *reinterpret_cast<const float4*>(e.gate + n);
+    }
+    // all LDS reads come first: in a kernel that also uses the LDS DMA the compiler fences every later LDS read with
+    // vmcnt(0), which would make each row wait for the previous row's global store
+    float4 vr[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) vr[it] = *reinterpret_cast<const float4*>(et + (it * 4 + rsub) * EP + c4);
+    float4 old[16];
+    if (EPI == 3) {
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = m0 + wm * 64 + it * 4 + rsub;
+            old[it] = (n < N && m < M) ? *reinterpret_cast<const float4*>(e.resid + (long)m * e.ldc + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int row = it * 4 + rsub, m = m0 + wm * 64 + row;
+        float4 v = vr[it];
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        if (n >= N || m >= M) continue;
+        if (EPI == 3) {
+            float4 o = old[it];
+            o.x = fmaf(gv.x, v.x, o.x); o.y = fmaf(gv.y, v.y, o.y); o.z = fmaf(gv.z, v.z, o.z); o.w = fmaf(gv.w, v.w, o.w);
+            *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + n) = o;
+        } else if (EPI == 2) {
+            *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
+        } else {
+            if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+            *reinterpret_cast<uint2*>((bf16_t*)e.out + (long)m * e.ldc + n) = pk;
+        }
+    }
 }
 
 // C[M,N] = A[M,K] W[N,K]^T.  128x128 block tile, 4 waves as 2x2, each wave 64x64 = 2x2 accumulators of
@@ -125,54 +185,175 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
         __syncthreads();
     }
 
-    // epilogue through LDS: the accumulator layout (column on the lane, rows in registers) would store 2-4 bytes
-    // per lane; each wave instead parks its 64x64 tile in LDS (the operand buffers are free now) and reads it
-    // back row-wise, so every lane moves 4 consecutive columns: 16 wide stores per lane instead of 64 narrow ones.
-    constexpr int EP = 68;                                   // fp32 pitch of the per-wave tile
-    float* et = reinterpret_cast<float*>(gm_smem) + wid * 64 * EP;
+    gemm_epilogue<EPI>(acc, gm_smem, e, M, N, m0, n0, wm, wn, wid, lane);
+}
+
+// 256x256x32 tile, 8 waves as 2 (M) x 4 (N), each wave 128x64 = 4x2 accumulators of v_mfma_f32_32x32x16_bf16,
+// operands copied global -> LDS by the DMA path (global_load_lds, 16 B per lane, no staging registers) into a ring of
+// four 32 KB stages that runs three K steps ahead.
+// Why this shape (measured on MI355X with tests/micro/gemm_bench at the DiT shapes, M = 6400): operand fetches take
+// ~1.5 us to land while every CU streams, so a CU's MFMA rate is (bytes it keeps in flight) x (flops per byte of tile)
+// / latency.  The 128x128x64 tile with one step of lookahead keeps 32 KB in flight per workgroup (K step 2.7k cycles
+// against 512 of MFMA); this ring keeps 96 KB in flight at twice the flops per byte.
+// The DMA writes a wave-instruction's 64 x 16 bytes linearly (16 rows of 64 B), so rows carry no padding; bank conflicts
+// are avoided by an XOR swizzle applied to the SOURCE chunk each lane fetches and to the fragment reads: chunk c of
+// row r lives at slot c ^ ((r >> 2) & 3).  Counted s_waitcnt vmcnt(8) + raw s_barrier keep two stages in flight across
+// the barrier (__syncthreads() would drain them).
+#define G2_STAGES 4
+#define G2_BK 32
+#define G2_STAGE_BYTES (2 * 256 * G2_BK * 2)                // A tile + B tile, 256 rows x 32 bf16 each
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
+    char* smem = reinterpret_cast<char*>(gm_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3, lr = lane & 31, kh = lane >> 5;
+    // XCD-aware tile order (see gemm_bf16_k)
+    const int ntn = N / 256, nwg = gridDim.x;
+    const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int m0 = (wg / ntn) * 256, n0 = (wg % ntn) * 256;
+
+    // wave-instruction i (of 2) of wave wid fills stage bytes [(wid*2+i)*1024, +1024) of the A (and B) tile:
+    // row = (wid*2+i)*16 + lane/4, slot = lane%4  ->  logical chunk = slot ^ ((row >> 2) & 3)
+    const bf16_t* a_src[2];
+    const bf16_t* b_src[2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wid * 2 + i) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        a_src[i] = A + (long)min(m0 + row, M - 1) * lda + c * 8;
+        b_src[i] = W + (long)min(n0 + row, N - 1) * K + c * 8;
+    }
+    auto issue = [&](int t) {
+        char* st = smem + (t % G2_STAGES) * G2_STAGE_BYTES + wid * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(a_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(b_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + 16384 + i * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) et[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * EP + ni * 32 + lr] = acc[mi][ni][r];
-    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the wave reads back only its own tile
-    __builtin_amdgcn_wave_barrier();
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // fragment read offsets inside a stage (bytes): row*64 + ((2ks + kh) ^ ((row>>2)&3))*16
+    int a_off[4], b_off[2], a_sw[4], b_sw[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int ra = wm * 128 + i * 32 + lr; a_off[i] = ra * 64; a_sw[i] = (ra >> 2) & 3; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int rb = wn * 64 + i * 32 + lr; b_off[i] = 16384 + rb * 64; b_sw[i] = (rb >> 2) & 3; }
+
+    const int nt = K / G2_BK;
+#pragma unroll
+    for (int t = 0; t < G2_STAGES - 1; ++t)
+        if (t < nt) issue(t);
+    for (int t = 0; t < nt; ++t) {
+        // stage t has landed once at most the stages issued after it are still outstanding (4 DMAs per stage per wave)
+        const int ahead = min(nt - 1 - t, G2_STAGES - 2);
+        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F78);        // vmcnt(8)
+        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+        __builtin_amdgcn_s_barrier();                               // everyone's part of stage t is in LDS; the slot of stage t-1 is free
+        if (t + G2_STAGES - 1 < nt) issue(t + G2_STAGES - 1);
+        const char* sb = smem + (t % G2_STAGES) * G2_STAGE_BYTES;
+        frag_ab fa[2][4], fb[2][2];
+        auto load_frags = [&](int ks, frag_ab (&a)[4], frag_ab (&b)[2]) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const frag_ab*>(sb + b_off[ni] + (((2 * ks + kh) ^ b_sw[ni]) << 4));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const frag_ab*>(sb + a_off[mi] + (((2 * ks + kh) ^ a_sw[mi]) << 4));
+        };
+        load_frags(0, fa[0], fb[0]);
+#pragma unroll
+        for (int ks = 0; ks < G2_BK / 16; ++ks) {
+            if (ks + 1 < G2_BK / 16) load_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mi], fb[ks & 1][ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                                // all waves are done with the ring: the epilogue parks tiles in it
+
+    // epilogue through LDS, a quarter of the wave's tile (32 rows x 64 columns) at a time: see gemm_epilogue
+    float* park = reinterpret_cast<float*>(smem) + wid * 32 * 68;
     const int c4 = (lane & 15) * 4, rsub = lane >> 4;
     const int n = n0 + wn * 64 + c4;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gv = bv;
-    if (n < N) {                                             // N % 4 == 0 is checked on the host
-        if (e.bias) bv = *reinterpret_cast<const float4*>(e.bias + n);
-        if (EPI == 3) gv = *reinterpret_cast<const float4*>(e.gate + n);
-    }
-    float4 old[16];
-    if (EPI == 3) {
+    if (e.bias) bv = *reinterpret_cast<const float4*>(e.bias + n);
+    if (EPI == 3) gv = *reinterpret_cast<const float4*>(e.gate + n);
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int m = m0 + wm * 64 + it * 4 + rsub;
-            old[it] = (n < N && m < M) ? *reinterpret_cast<const float4*>(e.resid + (long)m * e.ldc + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
+    for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int row = it * 4 + rsub, m = m0 + wm * 64 + row;
-        float4 v = *reinterpret_cast<const float4*>(et + row * EP + c4);
-        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-        if (n >= N || m >= M) continue;
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) park[((r & 3) + 8 * (r >> 2) + 4 * kh) * 68 + ni * 32 + lr] = acc[mi][ni][r];
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the wave reads back only its own quarter tile
+        __builtin_amdgcn_wave_barrier();
+        // the read-back is inline asm: in a kernel that uses the LDS DMA the compiler fences every LDS read it can see with
+        // vmcnt(0), which would make each quarter wait for the previous quarter's global stores to retire
+        f32x4 vq[8];
+        const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(park + rsub * 68 + c4);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vq[it]) : "v"(pa), "n"(it * 4 * 68 * 4) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vq[0]), "+v"(vq[1]), "+v"(vq[2]), "+v"(vq[3]), "+v"(vq[4]), "+v"(vq[5]), "+v"(vq[6]), "+v"(vq[7]) : : "memory");
+        float4 vr[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) vr[it] = make_float4(vq[it][0], vq[it][1], vq[it][2], vq[it][3]);
+        __builtin_amdgcn_wave_barrier();                         // the next quarter overwrites the park region
+        const int mb = m0 + wm * 128 + mi * 32 + rsub;
+        float4 old[8];
         if (EPI == 3) {
-            float4 o = old[it];
-            o.x = fmaf(gv.x, v.x, o.x); o.y = fmaf(gv.y, v.y, o.y); o.z = fmaf(gv.z, v.z, o.z); o.w = fmaf(gv.w, v.w, o.w);
-            *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + n) = o;
-        } else if (EPI == 2) {
-            *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
-        } else {
-            if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
-            uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-            pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-            *reinterpret_cast<uint2*>((bf16_t*)e.out + (long)m * e.ldc + n) = pk;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int m = min(mb + it * 4, M - 1);
+                old[it] = *reinterpret_cast<const float4*>(e.resid + (long)m * e.ldc + n);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = mb + it * 4;
+            float4 v = vr[it];
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (m >= M) continue;
+            if (EPI == 3) {
+                float4 o = old[it];
+                o.x = fmaf(gv.x, v.x, o.x); o.y = fmaf(gv.y, v.y, o.y); o.z = fmaf(gv.z, v.z, o.z); o.w = fmaf(gv.w, v.w, o.w);
+                *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + n) = o;
+            } else if (EPI == 2) {
+                *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
+            } else {
+                if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                *reinterpret_cast<uint2*>((bf16_t*)e.out + (long)m * e.ldc + n) = pk;
+            }
         }
     }
+}
+
+template <int EPI>
+static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)G2_STAGES * G2_STAGE_BYTES;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    dim3 grid((N / 256) * cdiv(M, 256));
+    hipLaunchKernelGGL((gemm256_k<EPI>), grid, dim3(512), lds, st, A, lda, W, M, N, K, epi);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
 }
 
 template <bool PRECISE, int EPI, int BM>
@@ -193,6 +374,11 @@ static int gemm_launch3(const void* A, int lda, const bf16_t* W, int M, int N, i
 // are used when they still fill the chip (>= 1 workgroup per CU) and the split operand of the precise form is off
 template <bool PRECISE, int EPI>
 static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
+    if (gemm_tile_override == 64) return gemm_launch3<PRECISE, EPI, 64>(A, lda, W, M, N, K, epi, st);
+    // 256x256 tiles pay ~10 us of prologue / epilogue bursts per tile and leave CUs idle on small grids: measured on
+    // MI355X they win once there are >= ~160 of them (M 6400: N 2048 44 vs 59 us, N 3072 71 vs 72 us, N 1024 35 vs 27 us)
+    if (!PRECISE && gemm_tile_override != 128 && N % 256 == 0 && K % G2_BK == 0 && (N / 256) * cdiv(M, 256) >= 160)
+        return gemm_launch_256<EPI>((const bf16_t*)A, lda, W, M, N, K, epi, st);
     return gemm_launch3<PRECISE, EPI, 128>(A, lda, W, M, N, K, epi, st);
 }
 
