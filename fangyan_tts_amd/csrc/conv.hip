@@ -11,10 +11,9 @@
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
-#ifndef FY_ABL
-#define FY_ABL 0
-#endif
-#if FY_ABL == 9
+// -DFY_CONV_STAMPS: wave 0 of every workgroup adds the cycles it spent in each phase of the MFMA kernel to fy_dbg[]
+// (tests/micro/conv_bench.hip prints the split); off in the library
+#ifdef FY_CONV_STAMPS
 __device__ unsigned long long fy_dbg[8];
 void conv_dbg_read(unsigned long long* out, bool reset) {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(fy_dbg), sizeof(fy_dbg));
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
     const int nrows = row_hi - row_lo + 1;
     const float* xb = d.x + (long)b * d.x_bs;
     char* lo_tile = smem + (size_t)nrows_max * MF_ROWB;
-#if FY_ABL == 9
+#ifdef FY_CONV_STAMPS
     long long _t = clock64();
 #endif
     const bool wave_live = n32_base < N32;          // whole wave beyond the group's channels: only helps staging
@@ -244,11 +243,7 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
                     const int row = row_lo + r, ci = ci0 + c4;
                     rr[u] = r; cc[u] = c4;
                     okk[u] = row >= 0 && row < n_in && ci < Cin_g;
-#if FY_ABL == 1
-                    vv[u] = make_float4(0.f, 0.f, 0.f, (float)idx);
-#else
                     vv[u] = *reinterpret_cast<const float4*>(xb + (long)min(max(row, 0), row_max) * d.x_ld + ci_base + min(ci, ci_max));
-#endif
                     aa[u] = make_float4(1.f, 1.f, 1.f, 1.f);
                     if (ACT == ACT_SNAKE) aa[u] = *reinterpret_cast<const float4*>(d.alpha + ci_base + min(ci, ci_max));
                 }
@@ -364,21 +359,12 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
         };
         frag_ab h0[KH][2], h1[KH][2];
         load_b(0, 0, h0);
-#if FY_ABL == 4
-        load_b(0, 1, h1);
-#endif
-#if FY_ABL != 2
         for (int t = 0; t < d.KW; ++t) {
-#if FY_ABL != 4
             load_b(t, 1, h1);
-#endif
             tap_half(t, 0, h0);
-#if FY_ABL != 4
             if (t + 1 < d.KW) load_b(t + 1, 0, h0);
-#endif
             tap_half(t, 1, h1);
         }
-#endif
         }
     }
     // epilogue through LDS: the accumulator layout (channel on the lane, positions in registers) would move 4 bytes
@@ -389,9 +375,6 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
     __syncthreads();                                         // every wave is done with the input tile
     DBG_T(4);
     if (!wave_live) return;
-#if FY_ABL == 3
-    if (acc[0][0][0] + acc[1][1][5] + acc[0][1][3] + acc[1][0][7] != 123.456f) return;
-#endif
     constexpr int EP = 68;                                   // fp32 pitch of the parked half tile
     float* et = reinterpret_cast<float*>(smem) + wid * 32 * EP;
     const float osc = d.out_scale;

@@ -1,5 +1,6 @@
 // Stand-alone microbenchmark of the HiFT resblock convolutions (one launch per shape).  Not part of the library.
-//   hipcc -O3 --offload-arch=gfx950 -I fangyan_tts_amd/csrc tests/micro/conv_bench.hip fangyan_tts_amd/csrc/{conv,runtime}.hip
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 [-DFY_CONV_STAMPS] -I fangyan_tts_amd/csrc -I include tests/micro/conv_bench.hip \
+//         fangyan_tts_amd/csrc/{conv,runtime}.hip -o tests/micro/conv_bench ;  conv_bench [1]   (1 = bf16 activation streams)
 #include "conv.h"
 #include "runtime.h"
 #include <functional>
@@ -7,7 +8,7 @@
 #include <stdlib.h>
 #include <vector>
 extern "C" const char* fy_last_error(void);
-#if FY_ABL == 9
+#ifdef FY_CONV_STAMPS
 void conv_dbg_read(unsigned long long* out, bool reset);
 #endif
 
@@ -61,7 +62,7 @@ int main(int argc, char** argv) {
         double el = (double)s.B * s.L * s.C;
         double gb = (streams ? el * (s.resid ? 2 + 4 + 4 + 2 : 4) : el * 4 * (2 + s.resid)) / 1e9, tf = 2.0 * el * s.C * s.KW / 1e12;
         printf("%-20s C %3d k %2d : %9.1f us  %6.2f TB/s (moved)  %6.1f TFLOP/s\n", s.name, s.C, s.KW, us, gb / us * 1e3, tf / us * 1e6);
-#if FY_ABL == 9
+#ifdef FY_CONV_STAMPS
         { unsigned long long t[8]; hipDeviceSynchronize(); conv_dbg_read(t, true);
           double tot = 0; for (int i = 0; i < 6; ++i) tot += t[i];
           printf("    wave0 cycles: pre-sync %.1f%%  stage %.1f%%  sync %.1f%%  taps %.1f%%  sync %.1f%%  epilogue %.1f%%   (%.0f cycles / WG)\n",
