@@ -6,9 +6,10 @@
 #include <stdlib.h>
 #include <vector>
 
+static int g_warm = 3;
 static float time_loop(hipStream_t st, int iters, const std::function<void()>& f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (int i = 0; i < 3; ++i) f();
+    for (int i = 0; i < g_warm; ++i) f();
     hipEventRecord(a, st);
     for (int i = 0; i < iters; ++i) f();
     hipEventRecord(b, st); hipEventSynchronize(b);
@@ -16,7 +17,8 @@ static float time_loop(hipStream_t st, int iters, const std::function<void()>& f
     return ms * 1e3f / iters;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool pmc = argc > 1;        // any argument: auto kernel choice only, 1 warm-up + 2 timed launches per shape (for rocprofv3 --pmc)
     hipStream_t st; hipStreamCreate(&st);
     const int Mmax = 12800, Nmax = 3072, Kmax = 2048;
     bf16_t *A, *W, *O; float *R, *bias;
@@ -34,13 +36,15 @@ int main() {
         {6400, 1024, 2048, 1, "ff2  gate-resid"}, {6400, 1024, 1024, 0, "out-shape bf16 out"}, {1280, 1024, 1024, 0, "M=1280 bf16 out"},
         {12800, 1024, 1024, 0, "M=12800 bf16 out"}, {6400, 1024, 320, 2, "in-proj f32 out"}};
     extern int gemm_tile_override;
-    for (int tile : {128, 0}) { gemm_tile_override = tile; printf("--- tile override %d (0 = DMA-pipelined kernel)\n", tile);
+    if (pmc) g_warm = 1;
+    for (int tile : {128, 0}) {
+        if (pmc && tile) continue; gemm_tile_override = tile; printf("--- tile override %d (0 = DMA-pipelined kernel)\n", tile);
     for (auto& s : shapes) {
         GemmEpi e;
         e.bias = bias;
         if (s.mode == 1) { e.mode = EPI_GATE_RESID; e.resid = R; e.gate = bias; e.ldc = s.N; }
         else { e.out = s.mode == 2 ? (void*)R : (void*)O; e.out_bf16 = s.mode != 2; e.ldc = s.N; e.act = s.mode == 0 && s.N == 2048 ? ACT_GELU_TANH : ACT_NONE; }
-        float us = time_loop(st, 30, [&] { gemm_bf16(A, s.K, W, s.M, s.N, s.K, e, st); });
+        float us = time_loop(st, pmc ? 2 : 30, [&] { gemm_bf16(A, s.K, W, s.M, s.N, s.K, e, st); });
         double gf = 2.0 * s.M * s.N * s.K / 1e9;
         printf("%-20s M %5d N %4d K %4d : %8.2f us  %7.1f TFLOP/s\n", s.name, s.M, s.N, s.K, us, gf / us);
     } }
