@@ -60,5 +60,5 @@ void conv_free(ConvW& cw);
 
 int conv1d_f32_direct(const ConvDesc& d, const ConvW& w, hipStream_t st);
 int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_t st);
-// exact fp32 on v_mfma_f32_32x32x2_f32 (w.w_dir layout); stride 1, one group, optional ELU
+// exact fp32 on v_mfma_f32_32x32x2_f32 (w.w_dir layout); stride 1, one group; bias, ELU / leaky-relu, residual add
 int conv1d_f32_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st);

@@ -623,6 +623,8 @@ __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvDesc d, const float
                 if (p >= n_out) continue;
                 float v = acc[mi][ni][r] + bv;
                 if (POST == ACT_ELU) v = act_elu(v);
+                if (POST == ACT_LEAKY) v = act_leaky(v, d.post_slope);
+                if (d.add_resid) v += d.resid[(long)b * d.r_bs + (long)p * d.r_ld + co];
                 yb[(long)p * d.y_ld + co] = v;
             }
     }
@@ -631,13 +633,14 @@ __global__ __launch_bounds__(256) void conv1d_f32_mfma_k(ConvDesc d, const float
 int conv1d_f32_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st) {
     FY_CHECK(w.w_dir != nullptr, FY_ERR_STATE, "conv1d_f32_mfma: weights not packed in the fp32 layout");
     FY_CHECK(d.Cin == w.Cin && d.Cout == w.Cout && d.KW == w.KW && d.groups == 1 && w.groups == 1, FY_ERR_ARG, "conv1d_f32_mfma: descriptor != weights");
-    FY_CHECK(d.stride == 1 && d.up == 1 && d.dil >= 1 && d.B >= 1 && d.L_out >= 1 && !d.add_resid && !d.accumulate && !d.reflect1 &&
-             d.pre_act != ACT_SNAKE && (d.post_act == ACT_NONE || d.post_act == ACT_ELU) && d.Cin % 4 == 0 && d.x_ld % 4 == 0 && d.x_bs % 4 == 0 &&
+    FY_CHECK(d.stride == 1 && d.up == 1 && d.dil >= 1 && d.B >= 1 && d.L_out >= 1 && !d.accumulate && !d.reflect1 && d.out_scale == 1.f &&
+             d.pre_act != ACT_SNAKE && (d.post_act == ACT_NONE || d.post_act == ACT_ELU || d.post_act == ACT_LEAKY) && d.Cin % 4 == 0 && d.x_ld % 4 == 0 && d.x_bs % 4 == 0 &&
              ((uintptr_t)d.x & 15) == 0, FY_ERR_ARG, "conv1d_f32_mfma: unsupported fusion / geometry / alignment");
     const size_t lds = (size_t)(FM_TP + (d.KW - 1) * d.dil) * FM_PITCH * sizeof(float);
     FY_CHECK(lds <= 64 * 1024, FY_ERR_ARG, "conv1d_f32_mfma: input tile needs %zu B of LDS", lds);
     dim3 grid(cdiv(d.L_out, FM_TP), cdiv(d.Cout, FM_TC), d.B);
     if (d.post_act == ACT_ELU) hipLaunchKernelGGL(conv1d_f32_mfma_k<ACT_ELU>, grid, dim3(256), lds, st, d, w.w_dir, w.cout_pad4());
+    else if (d.post_act == ACT_LEAKY) hipLaunchKernelGGL(conv1d_f32_mfma_k<ACT_LEAKY>, grid, dim3(256), lds, st, d, w.w_dir, w.cout_pad4());
     else hipLaunchKernelGGL(conv1d_f32_mfma_k<ACT_NONE>, grid, dim3(256), lds, st, d, w.w_dir, w.cout_pad4());
     HIP_TRY(hipGetLastError());
     return FY_OK;

@@ -444,7 +444,7 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
         d.y = f->pre_a; d.y_bs = (long)Nmax * c.pre_ch; d.y_ld = c.pre_ch; d.L_out = Nmax; d.out_len = d_nall;
         d.Cin = C; d.Cout = c.pre_ch; d.KW = c.pre_lookahead + 1; d.pad_left = 0; d.bias = f->pre1.bias;
         d.post_act = ACT_LEAKY; d.post_slope = 0.01f;
-        FY_TRY(conv1d_f32_direct(d, f->pre1, st));
+        FY_TRY(conv1d_f32_mfma(d, f->pre1, st));
         ConvDesc e;
         memset(&e, 0, sizeof(e));
         e.B = B; e.dil = 1; e.stride = 1; e.up = 1; e.groups = 1; e.out_scale = 1.f;
@@ -452,7 +452,7 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
         e.y = f->mu_tok; e.y_bs = (long)Nmax * C; e.y_ld = C; e.L_out = Nmax; e.out_len = d_nall;
         e.Cin = c.pre_ch; e.Cout = C; e.KW = 3; e.pad_left = 2; e.bias = f->pre2.bias;
         e.add_resid = 1; e.resid = f->emb; e.r_bs = (long)Nmax * C; e.r_ld = C;
-        FY_TRY(conv1d_f32_direct(e, f->pre2, st));
+        FY_TRY(conv1d_f32_mfma(e, f->pre2, st));
     }
     hipLaunchKernelGGL(flow_setup_k, dim3(Tmax, B), dim3(128), 0, st, f->mu_tok, prompt_feat, (long)pfeat_rows * C, rand_noise, noise_ld, d_T,
                        d_pmel, f->mu, f->cond, f->x, Tmax, Nmax, C);
