@@ -42,6 +42,7 @@ class LlmConfig(C.Structure):
 FY_PRECISE = 1
 FY_DIRECT = 2
 FY_STREAMING = 4
+FY_NO_FINALIZE = 8
 FY_LLM_KEEP_LOGP = 4
 
 _lib = None

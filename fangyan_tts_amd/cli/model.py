@@ -165,6 +165,58 @@ class CosyVoice3Model:
         self.last_mel, self.last_frames = mel, frames        # kept for parity tests / debugging
         return wav, [f * self.cfg.hift.upsample_total for f in frames]
 
+    # ------------------------------------------------------------------ stream=True (cli/model.py:339-369, 416-441)
+    token_hop_len = 25                                          # cli/model.py:401: "must match training static_chunk_size"
+
+    @torch.inference_mode()
+    def _tts_stream(self, d: Dict[str, torch.Tensor]):
+        """The reference's chunk schedule: a chunk is cut whenever `hop + pre_lookahead` tokens beyond the offset exist (the
+        first hop is padded so prompt + hop is a multiple of 25); every chunk re-runs the flow decoder over all tokens so far
+        (chunk attention mask, finalize=False) and the vocoder over the whole mel so far (finalize=False), and yields the
+        samples beyond those already yielded; the last call is finalize=True without the chunk mask.  The chunk boundaries
+        depend only on the token count, so decoding the whole token sequence first (one device-side loop here) yields the
+        same chunks as the reference's polling loop."""
+        z = torch.zeros(1, 0, dtype=torch.int32)
+        text = [d["text"].reshape(-1).tolist()]
+        ptext = [d.get("prompt_text", z).reshape(-1).tolist()]
+        pspeech = [d.get("llm_prompt_speech_token", z).reshape(-1).tolist()]
+        fp = d["flow_prompt_speech_token"].reshape(1, -1).to(torch.int32)
+        pf = d["prompt_speech_feat"].reshape(1, -1, 80).float()
+        emb = d["flow_embedding"].reshape(1, -1).float()
+        n_fp, n_pf = fp.shape[1], pf.shape[1]
+        ptok = fp if n_fp else torch.zeros(1, 1, dtype=torch.int32)
+        pfeat = pf if n_pf else torch.zeros(1, 1, 80)
+        look, hop0 = self.cfg.flow.pre_lookahead, self.token_hop_len
+        up = self.cfg.hift.upsample_total
+        with self.lock:
+            out, out_n, _ = self.llm.generate(text, ptext, pspeech)
+            n = int(out_n.cpu()[0])
+            if n < 1:
+                raise RuntimeError("the language model emitted no speech token for an utterance")
+            pad = -(-n_fp // hop0) * hop0 - n_fp
+            offset, speech_offset, mel_all = 0, 0, None
+
+            def token2wav(n_in, offset, mel_all, speech_offset, streaming, finalize):
+                mel = self.flow.inference(out[:, :n_in], [n_in], ptok, [n_fp], pfeat, [n_pf], emb, self.rand_noise,
+                                          streaming=streaming, finalize=finalize)
+                valid = 2 * (n_in if finalize else n_in - look)
+                mel = mel[:, :, 2 * offset: valid]
+                mel_all = mel if mel_all is None else torch.cat([mel_all, mel], dim=2)
+                wav, _ = self.hift.inference(mel_all.contiguous(), self.rand_ini, self.sine_noise, finalize=finalize)
+                end = up * (mel_all.shape[2] if finalize else mel_all.shape[2] - 8)
+                return wav[:, speech_offset:end], mel_all, end
+
+            while True:
+                hop = hop0 + pad if offset == 0 else hop0
+                if n - offset < hop + look:
+                    break
+                wav, mel_all, speech_offset = token2wav(offset + hop + look, offset, mel_all, speech_offset, True, False)
+                offset += hop
+                yield {"tts_speech": wav.cpu()}
+            wav, mel_all, speech_offset = token2wav(n, offset, mel_all, speech_offset, False, True)
+            self.last_mel, self.last_frames = mel_all, [mel_all.shape[2]]
+            yield {"tts_speech": wav.cpu()}
+
     # ------------------------------------------------------------------ reference-shaped path
     def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192), llm_embedding=torch.zeros(0, 192),
             prompt_text=torch.zeros(1, 0, dtype=torch.int32), llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
@@ -173,7 +225,10 @@ class CosyVoice3Model:
         if source_speech_token.shape[1] != 0:
             raise NotImplementedError("voice conversion (inference_vc) is not part of this build")
         if stream:
-            raise NotImplementedError("stream=True is not built yet (SURVEY 8 f3); use stream=False")
+            yield from self._tts_stream(dict(text=text, prompt_text=prompt_text, llm_prompt_speech_token=llm_prompt_speech_token,
+                                             flow_prompt_speech_token=flow_prompt_speech_token,
+                                             prompt_speech_feat=prompt_speech_feat, flow_embedding=flow_embedding))
+            return
         wav, samples, _ = self.tts_batch([dict(text=text, prompt_text=prompt_text, llm_prompt_speech_token=llm_prompt_speech_token,
                                                flow_prompt_speech_token=flow_prompt_speech_token,
                                                prompt_speech_feat=prompt_speech_feat, flow_embedding=flow_embedding)], speed=speed)

@@ -34,7 +34,7 @@ struct fy_flow {
     float2* rope = nullptr;    // [Tmax][head_dim/2] (cos, sin)
     std::vector<float> t_of_step, dt_of_step;
     // activations
-    int *tok_all, *seq_len, *blen;     // blen: [4][max_batch] = n_all tokens, T, pmel, (unused)
+    int *tok_all, *seq_len, *blen;     // blen: [5][max_batch] = n_all tokens, T, pmel, prompt tokens, tokens PreLookahead outputs
     float *emb, *pre_a, *mu_tok, *spks, *x, *mu, *cond, *h, *c1, *v, *temb, *tsil, *gpart;
     bf16_t *a_in, *xn, *qkv, *ao, *ff;
     ~fy_flow() { conv_free(pre1); conv_free(pre2); conv_free(pos1); conv_free(pos2); }
@@ -310,7 +310,7 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
     }
     // activations
     const size_t B = max_batch, T = f->Tmax, N = f->Nmax, M = 2 * B * T;
-    TRYC(f->pool.alloc(&f->tok_all, B * N)); TRYC(f->pool.alloc(&f->seq_len, 2 * B)); TRYC(f->pool.alloc(&f->blen, 4 * B));
+    TRYC(f->pool.alloc(&f->tok_all, B * N)); TRYC(f->pool.alloc(&f->seq_len, 2 * B)); TRYC(f->pool.alloc(&f->blen, 5 * B));
     TRYC(f->pool.alloc(&f->emb, B * N * C)); TRYC(f->pool.alloc(&f->pre_a, B * N * c.pre_ch)); TRYC(f->pool.alloc(&f->mu_tok, B * N * C));
     TRYC(f->pool.alloc(&f->spks, B * C)); TRYC(f->pool.alloc(&f->x, B * T * C)); TRYC(f->pool.alloc(&f->mu, B * T * C));
     TRYC(f->pool.alloc(&f->cond, B * T * C)); TRYC(f->pool.alloc(&f->h, M * D)); TRYC(f->pool.alloc(&f->c1, M * D));
@@ -416,22 +416,25 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
     FY_CHECK(B >= 1 && B <= f->max_batch, FY_ERR_ARG, "fy_flow_infer: batch %d outside [1, %d]", B, f->max_batch);
     const fy_flow_config& c = f->cfg;
     const int C = c.mel, mb = f->max_batch;
-    std::vector<int> lens(4 * mb, 0), sl(2 * mb, 0), npr(mb, 0);
+    std::vector<int> lens(5 * mb, 0), sl(2 * mb, 0), npr(mb, 0);
+    // a streaming chunk (finalize=False, flow.py:382-383): the last pre_lookahead tokens are PreLookahead's context, not output
+    const int look = (flags & FY_NO_FINALIZE) ? c.pre_lookahead : 0;
     int Tmax = 0, Nmax = 0;
     for (int b = 0; b < B; ++b) {
-        int n_all = n_token[b] + n_prompt[b], T = 2 * n_all;
-        FY_CHECK(n_token[b] >= 1 && n_prompt[b] >= 0 && n_pfeat[b] >= 0 && n_pfeat[b] <= T && T <= f->Tmax && T <= noise_ld &&
-                     2 * n_token[b] <= mel_frames && n_token[b] <= tok_ld && n_prompt[b] <= ptok_ld && n_pfeat[b] <= pfeat_rows,
+        int n_all = n_token[b] + n_prompt[b], T = 2 * (n_all - look);
+        FY_CHECK(n_token[b] >= 1 + look && n_prompt[b] >= 0 && n_pfeat[b] >= 0 && n_pfeat[b] <= T && T <= f->Tmax && T <= noise_ld &&
+                     T - n_pfeat[b] <= mel_frames && n_token[b] <= tok_ld && n_prompt[b] <= ptok_ld && n_pfeat[b] <= pfeat_rows,
                  FY_ERR_ARG, "fy_flow_infer: utterance %d has inconsistent lengths (tokens %d, prompt %d, prompt frames %d, max frames %d)",
                  b, n_token[b], n_prompt[b], n_pfeat[b], f->Tmax);
         lens[0 * mb + b] = n_all; lens[1 * mb + b] = T; lens[2 * mb + b] = n_pfeat[b]; lens[3 * mb + b] = n_prompt[b];
+        lens[4 * mb + b] = n_all - look;
         sl[2 * b] = sl[2 * b + 1] = T;
         Tmax = std::max(Tmax, T); Nmax = std::max(Nmax, n_all);
     }
     HIP_TRY(hipMemcpyAsync(f->blen, lens.data(), lens.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(f->seq_len, sl.data(), sl.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    const int *d_nall = f->blen, *d_T = f->blen + mb, *d_pmel = f->blen + 2 * mb, *d_np = f->blen + 3 * mb;
+    const int *d_nall = f->blen, *d_T = f->blen + mb, *d_pmel = f->blen + 2 * mb, *d_np = f->blen + 3 * mb, *d_nout = f->blen + 4 * mb;
     // front: speaker projection, token embedding, PreLookahead (upsample_encoder.py:82-103)
     hipLaunchKernelGGL(spk_k, dim3(B), dim3(256), 0, st, embedding, f->spk_w, f->spk_b, f->spks, c.spk_in, C);
     hipLaunchKernelGGL(tok_embed_k, dim3(Nmax, B), dim3(128), 0, st, prompt_token, ptok_ld, token, tok_ld, d_np, d_nall, f->tok_all,
@@ -441,15 +444,15 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
         memset(&d, 0, sizeof(d));
         d.B = B; d.dil = 1; d.stride = 1; d.up = 1; d.groups = 1; d.out_scale = 1.f;
         d.x = f->emb; d.x_bs = (long)Nmax * C; d.x_ld = C; d.L_in = Nmax; d.in_len = d_nall;
-        d.y = f->pre_a; d.y_bs = (long)Nmax * c.pre_ch; d.y_ld = c.pre_ch; d.L_out = Nmax; d.out_len = d_nall;
+        d.y = f->pre_a; d.y_bs = (long)Nmax * c.pre_ch; d.y_ld = c.pre_ch; d.L_out = Nmax; d.out_len = d_nout;
         d.Cin = C; d.Cout = c.pre_ch; d.KW = c.pre_lookahead + 1; d.pad_left = 0; d.bias = f->pre1.bias;
         d.post_act = ACT_LEAKY; d.post_slope = 0.01f;
         FY_TRY(conv1d_f32_mfma(d, f->pre1, st));
         ConvDesc e;
         memset(&e, 0, sizeof(e));
         e.B = B; e.dil = 1; e.stride = 1; e.up = 1; e.groups = 1; e.out_scale = 1.f;
-        e.x = f->pre_a; e.x_bs = (long)Nmax * c.pre_ch; e.x_ld = c.pre_ch; e.L_in = Nmax; e.in_len = d_nall;
-        e.y = f->mu_tok; e.y_bs = (long)Nmax * C; e.y_ld = C; e.L_out = Nmax; e.out_len = d_nall;
+        e.x = f->pre_a; e.x_bs = (long)Nmax * c.pre_ch; e.x_ld = c.pre_ch; e.L_in = Nmax; e.in_len = d_nout;
+        e.y = f->mu_tok; e.y_bs = (long)Nmax * C; e.y_ld = C; e.L_out = Nmax; e.out_len = d_nout;
         e.Cin = c.pre_ch; e.Cout = C; e.KW = 3; e.pad_left = 2; e.bias = f->pre2.bias;
         e.add_resid = 1; e.resid = f->emb; e.r_bs = (long)Nmax * C; e.r_ld = C;
         FY_TRY(conv1d_f32_mfma(e, f->pre2, st));
@@ -463,7 +466,7 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
     }
     // mel[b] = x[b][pmel:, :]^T in the reference's (B, 80, F) layout, flow.py:401
     for (int b = 0; b < B; ++b) {
-        int F = 2 * n_token[b];
+        int F = 2 * (n_token[b] + n_prompt[b] - look) - n_pfeat[b];       // mel_len2 = h.shape[1] - prompt_feat.shape[1], flow.py:384
         FY_TRY(transpose_blc_to_bcl(f->x + ((long)b * Tmax + n_pfeat[b]) * C, mel + (long)b * C * mel_frames, 1, C, F, 0, C, 0, mel_frames, st));
     }
     HIP_TRY(hipGetLastError());

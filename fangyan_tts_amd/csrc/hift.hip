@@ -35,7 +35,7 @@ struct fy_hift {
     int sb_ld[N_UP] = {0, 0, 0};
     ConvW sd_mfma[N_UP];
     ConvW ups_poly[N_UP];                            // ups[i] in polyphase form (conv_pack_polyphase)
-    int *lens;                                       // device: [6][max_batch] = F, L0, L1, L2conv, L2, S
+    int *lens;                                       // device: [8][max_batch] = F, L0, L1, L2conv, L2, S_out, F_f0, F_dec (set_lens)
     int B = 0, Fmax = 0;                             // of the last call (for taps)
     int L(int stage, int F) const {                  // rows of stage tensors for F frames
         int l = F;
@@ -206,7 +206,7 @@ extern "C" int fy_hift_create(fy_hift** out, const fy_hift_config* cfg, const fy
     }
     for (int i = 0; i < N_UP; ++i)
         if (h->sb_ld[i]) TRYC(h->pool.alloc(&h->sb[i], B * ((size_t)h->L(i, (int)F) + 1) * h->sb_ld[i]));
-    TRYC(h->pool.alloc(&h->lens, 6 * B));
+    TRYC(h->pool.alloc(&h->lens, 8 * B));
 #undef TRYC
     if (hipStreamSynchronize(st) != hipSuccess) { fy_set_error("fy_hift_create: stream sync failed"); return fail(FY_ERR_HIP); }
     *out = h;
@@ -284,11 +284,11 @@ struct SuperRows {                                   // bf16 super-row copies of
 // and the same rows, rounded to bf16, in the super-row layouts of the source down-samplers (super_pack_k): row tt lands in
 // S'[ceil(tt/s)] at position tt - s*ceil(tt/s) + s - 1; the thread that writes a super-row's last position also zeroes its
 // padding channels, and row 0's thread the s-1 positions before it (the conv's left zero padding).
-__global__ void stft16_k(const float* __restrict__ src, float* __restrict__ out, const int* __restrict__ frames, int Fmax, int up, int spf,
-                         SuperRows sr) {
+__global__ void stft16_k(const float* __restrict__ src, float* __restrict__ out, const int* __restrict__ frames_src,
+                         const int* __restrict__ frames, int Fmax, int up, int spf, SuperRows sr) {
     int b = blockIdx.y;
     int tt = blockIdx.x * 256 + threadIdx.x;
-    int S = frames[b] * up;
+    int S = frames_src[b] * up;               // samples of source (the reflect bound); a streaming chunk keeps fewer STFT frames
     int T = frames[b] * spf + 1;
     if (tt >= T) return;
     const float* s = src + (long)b * Fmax * up;
@@ -354,11 +354,11 @@ __global__ void spec_k(const float* __restrict__ post, float* __restrict__ spec,
 }
 
 // torch.istft(center=True) + clamp, generator.py:503-505, 710: one thread per output sample.
-__global__ void istft16_k(const float* __restrict__ spec, float* __restrict__ wav, const int* __restrict__ frames, int Fmax, int up, int spf, float limit) {
+__global__ void istft16_k(const float* __restrict__ spec, float* __restrict__ wav, const int* __restrict__ frames, const int* __restrict__ s_out,
+                          int Fmax, int up, int spf, float limit) {
     int b = blockIdx.y;
     long n = blockIdx.x * 256L + threadIdx.x;
-    long S = (long)frames[b] * up;
-    if (n >= S) return;
+    if (n >= s_out[b]) return;                // a streaming chunk holds its last frame of samples back
     int T = frames[b] * spf + 1;
     int m = (int)n + 8;                       // index in the un-trimmed overlap-add buffer
     int t_hi = min(m / 4, T - 1);
@@ -398,20 +398,30 @@ static int init_tables() {
 }
 
 // ---- orchestration -----------------------------------------------------------------
-static int set_lens(fy_hift* h, const int32_t* frames, int B, int Fmax, hipStream_t st) {
+// Per-utterance row counts of every stage.  finalize (the whole utterance): everything follows F.  A streaming chunk
+// (finalize = false, generator.py:674-679, 708-709, 722-725; f0_predictor.py:98-99) spends its last frames as look-ahead
+// instead of zero padding: the f0 predictor's first conv takes 3 (F_f0 = F - 3 frames of f0 / source), conv_pre another 4
+// of those (F_dec = F - 7 decoder frames) and the last frame of samples is held back (S_out = 480 (F - 8)).
+static int set_lens(fy_hift* h, const int32_t* frames, int B, int Fmax, hipStream_t st, bool finalize = true) {
     FY_CHECK(h && frames && B >= 1 && B <= h->max_batch && Fmax >= 1 && Fmax <= h->max_frames, FY_ERR_ARG,
              "hift: batch %d / frames %d outside the handle's limits (%d, %d)", B, Fmax, h ? h->max_batch : 0, h ? h->max_frames : 0);
-    std::vector<int> v(6 * h->max_batch, 0);
+    const int look_f0 = h->w.f0c[0].KW - 1, look_pre = h->cfg.pre_look_right;
+    std::vector<int> v(8 * h->max_batch, 0);
     for (int b = 0; b < B; ++b) {
         int F = frames[b];
         FY_CHECK(F >= 1 && F <= Fmax, FY_ERR_ARG, "hift: frames[%d] = %d outside [1, %d]", b, F, Fmax);
+        FY_CHECK(finalize || F >= look_f0 + look_pre + 2, FY_ERR_ARG, "hift: a streaming chunk needs at least %d frames (got %d)",
+                 look_f0 + look_pre + 2, F);
+        const int Ff0 = finalize ? F : F - look_f0, Fd = finalize ? F : Ff0 - look_pre;
         int mb = h->max_batch;
         v[0 * mb + b] = F;
-        v[1 * mb + b] = F * h->cfg.ups[0];
-        v[2 * mb + b] = F * h->cfg.ups[0] * h->cfg.ups[1];
-        v[3 * mb + b] = F * h->stft_per_frame;          // stage-2 conv rows before the reflect pad
-        v[4 * mb + b] = F * h->stft_per_frame + 1;
-        v[5 * mb + b] = F * h->up_total;
+        v[1 * mb + b] = Fd * h->cfg.ups[0];
+        v[2 * mb + b] = Fd * h->cfg.ups[0] * h->cfg.ups[1];
+        v[3 * mb + b] = Fd * h->stft_per_frame;          // stage-2 conv rows before the reflect pad
+        v[4 * mb + b] = Fd * h->stft_per_frame + 1;
+        v[5 * mb + b] = (finalize ? Fd : Fd - 1) * h->up_total;
+        v[6 * mb + b] = Ff0;
+        v[7 * mb + b] = Fd;
     }
     HIP_TRY(hipMemcpyAsync(h->lens, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));       // v goes out of scope
@@ -433,22 +443,23 @@ static int run_conv(const ConvDesc& d, const ConvW& w, uint32_t flags, hipStream
 
 static int hift_f0(fy_hift* h, int B, int Fmax, hipStream_t st) {
     const fy_hift_config& c = h->cfg;
-    const int* lF = h->lens;
+    const int* lF = h->lens;                               // mel frames
+    const int* lF0 = h->lens + 6 * h->max_batch;           // f0 frames (= mel frames unless a streaming chunk)
     // condnet[0]: k4, 3 frames of right look-ahead; then 4x k3 left-causal; ELU after each (f0_predictor.py:74-90)
     const float* in = h->mel_cl;
     int in_ld = c.mel;
     float* bufs[2] = {h->f0a, h->f0b};
     for (int i = 0; i < 5; ++i) {
         ConvDesc d = base_desc(B);
-        d.x = in; d.x_bs = (long)Fmax * in_ld; d.x_ld = in_ld; d.L_in = Fmax; d.in_len = lF;
-        d.y = bufs[i & 1]; d.y_bs = (long)Fmax * c.f0_ch; d.y_ld = c.f0_ch; d.L_out = Fmax; d.out_len = lF;
+        d.x = in; d.x_bs = (long)Fmax * in_ld; d.x_ld = in_ld; d.L_in = Fmax; d.in_len = i == 0 ? lF : lF0;
+        d.y = bufs[i & 1]; d.y_bs = (long)Fmax * c.f0_ch; d.y_ld = c.f0_ch; d.L_out = Fmax; d.out_len = lF0;
         d.Cin = i == 0 ? c.mel : c.f0_ch; d.Cout = c.f0_ch; d.KW = h->w.f0c[i].KW;
         d.pad_left = i == 0 ? 0 : (d.KW - 1);
         d.bias = h->w.f0c[i].bias; d.post_act = ACT_ELU;
         FY_TRY(conv1d_f32_mfma(d, h->w.f0c[i], st));
         in = bufs[i & 1]; in_ld = c.f0_ch;
     }
-    hipLaunchKernelGGL(f0_classifier_k, dim3(cdiv(Fmax, 4), B), dim3(256), 0, st, in, h->cls_w, h->cls_b, h->f0, lF, Fmax, c.f0_ch);
+    hipLaunchKernelGGL(f0_classifier_k, dim3(cdiv(Fmax, 4), B), dim3(256), 0, st, in, h->cls_w, h->cls_b, h->f0, lF0, Fmax, c.f0_ch);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -457,10 +468,10 @@ static int hift_source(fy_hift* h, const float* f0, int B, int Fmax, const float
     const fy_hift_config& c = h->cfg;
     (void)rand_ini;   // provably without effect on the output (see sine_phase_k); kept in the ABI for fidelity
     const int H1 = c.harmonics + 1;
-    hipLaunchKernelGGL(sine_phase_k, dim3(B), dim3(64), 0, st, f0, h->rad_phase, h->lens, Fmax, H1, (float)c.sampling_rate,
+    hipLaunchKernelGGL(sine_phase_k, dim3(B), dim3(64), 0, st, f0, h->rad_phase, h->lens + 6 * h->max_batch, Fmax, H1, (float)c.sampling_rate,
                        c.nsf_alpha, (float)h->up_total);
     hipLaunchKernelGGL(source_k, dim3(cdiv(Fmax * h->up_total, 256), B), dim3(256), 0, st, f0, h->rad_phase, sine_noise, h->lin_w,
-                       h->lin_b, h->source, h->lens, Fmax, H1, h->up_total, c.voiced_thr, c.nsf_sigma, c.nsf_alpha);
+                       h->lin_b, h->source, h->lens + 6 * h->max_batch, Fmax, H1, h->up_total, c.voiced_thr, c.nsf_sigma, c.nsf_alpha);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -531,17 +542,17 @@ static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, 
         sr.p[i] = streams ? h->sb[i] : nullptr; sr.s[i] = s; sr.ld[i] = h->sb_ld[i];
         sr.bs[i] = ((long)h->L(i, Fmax) + 1) * h->sb_ld[i];
     }
-    hipLaunchKernelGGL(stft16_k, dim3(cdiv(Tmax, 256), B), dim3(256), 0, st, h->source, h->s_stft, h->lens, Fmax, up, spf, sr);
+    hipLaunchKernelGGL(stft16_k, dim3(cdiv(Tmax, 256), B), dim3(256), 0, st, h->source, h->s_stft, h->lens + 6 * mb, h->lens + 7 * mb, Fmax, up, spf, sr);
     {   // conv_pre: k5, 4 frames of right look-ahead (generator.py:621-623, 675)
         ConvDesc d = base_desc(B);
-        d.x = h->mel_cl; d.x_bs = (long)Fmax * c.mel; d.x_ld = c.mel; d.L_in = Fmax; d.in_len = h->lens;
-        d.y = h->x_pre; d.y_bs = (long)Fmax * c.base; d.y_ld = c.base; d.L_out = Fmax; d.out_len = h->lens;
+        d.x = h->mel_cl; d.x_bs = (long)Fmax * c.mel; d.x_ld = c.mel; d.L_in = Fmax; d.in_len = h->lens + 6 * mb;
+        d.y = h->x_pre; d.y_bs = (long)Fmax * c.base; d.y_ld = c.base; d.L_out = Fmax; d.out_len = h->lens + 7 * mb;
         d.Cin = c.mel; d.Cout = c.base; d.KW = c.pre_look_right + 1; d.pad_left = 0; d.bias = h->w.conv_pre.bias;
         FY_TRY(run_conv(d, h->w.conv_pre, flags, st));
     }
     const float* xin = h->x_pre;
     int Cin = c.base, Lin_max = Fmax;
-    const int* len_in = h->lens;
+    const int* len_in = h->lens + 7 * mb;
     for (int i = 0; i < N_UP; ++i) {
         const int C = h->C(i);
         const int Lmax = h->L(i, Fmax);
@@ -599,8 +610,8 @@ static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, 
         FY_TRY(run_conv(d, h->w.conv_post, flags, st));
     }
     // the spectrum overwrites s_stft (no longer needed)
-    hipLaunchKernelGGL(spec_k, dim3(cdiv(Tmax * 9, 256), B), dim3(256), 0, st, h->post, h->s_stft, h->lens, Fmax, spf);
-    hipLaunchKernelGGL(istft16_k, dim3(cdiv(Fmax * up, 256), B), dim3(256), 0, st, h->s_stft, wav, h->lens, Fmax, up, spf, c.audio_limit);
+    hipLaunchKernelGGL(spec_k, dim3(cdiv(Tmax * 9, 256), B), dim3(256), 0, st, h->post, h->s_stft, h->lens + 7 * mb, Fmax, spf);
+    hipLaunchKernelGGL(istft16_k, dim3(cdiv(Fmax * up, 256), B), dim3(256), 0, st, h->s_stft, wav, h->lens + 7 * mb, h->lens + 5 * mb, Fmax, up, spf, c.audio_limit);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -613,7 +624,7 @@ extern "C" int fy_hift_infer(fy_hift* h, const float* mel, const int32_t* frames
                              const float* sine_noise, float* wav, float* source, uint32_t flags, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     FY_CHECK(h && mel && sine_noise && wav, FY_ERR_ARG, "fy_hift_infer: null argument");
-    FY_TRY(set_lens(h, frames, B, Fmax, st));
+    FY_TRY(set_lens(h, frames, B, Fmax, st, !(flags & FY_NO_FINALIZE)));
     FY_TRY(load_mel(h, mel, B, Fmax, st));
     FY_TRY(hift_f0(h, B, Fmax, st));
     FY_TRY(hift_source(h, h->f0, B, Fmax, rand_ini, sine_noise, st));

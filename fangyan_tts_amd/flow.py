@@ -9,7 +9,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import FY_DIRECT, FY_PRECISE, FY_STREAMING, check  # noqa: F401
+from ._lib import FY_DIRECT, FY_NO_FINALIZE, FY_PRECISE, FY_STREAMING, check  # noqa: F401
 from .spec import FlowCfg
 
 
@@ -65,9 +65,15 @@ class FlowEngine:
 
     def inference(self, token: torch.Tensor, n_token: Sequence[int], prompt_token: torch.Tensor, n_prompt: Sequence[int],
                   prompt_feat: torch.Tensor, n_pfeat: Sequence[int], embedding: torch.Tensor, rand_noise: torch.Tensor,
-                  flags: int = 0) -> torch.Tensor:
+                  flags: int = 0, streaming: bool = False, finalize: bool = True) -> torch.Tensor:
         """token (B, Nmax) int32, prompt_token (B, Pmax) int32, prompt_feat (B, PMmax, 80), embedding (B, 192),
-        rand_noise (1|-, 80, >=T) -> mel (B, 80, 2*max(n_token)); utterance b is valid in [:, :, :2*n_token[b]]."""
+        rand_noise (1|-, 80, >=T) -> mel (B, 80, 2*max(n_token)); utterance b is valid in [:, :, :2*n_token[b]].
+        streaming / finalize as in the reference (flow.py:358-403): the chunk attention mask, and the last
+        pre_lookahead tokens as look-ahead context only (valid frames 2*(n_token[b] - pre_lookahead))."""
+        if streaming:
+            flags |= FY_STREAMING
+        if not finalize:
+            flags |= FY_NO_FINALIZE
         B = token.shape[0]
         dev = self.device
         token = token.to(dev, torch.int32).contiguous()

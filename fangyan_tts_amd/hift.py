@@ -12,7 +12,7 @@ from typing import Dict, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import FY_DIRECT, FY_PRECISE, check  # noqa: F401
+from ._lib import FY_DIRECT, FY_NO_FINALIZE, FY_PRECISE, check  # noqa: F401
 from .spec import HiftCfg
 
 
@@ -68,9 +68,13 @@ class HiftEngine:
         return mel, B, Fmax, _lib.int_array(frames)
 
     def inference(self, speech_feat: torch.Tensor, rand_ini: torch.Tensor, sine_noise: torch.Tensor,
-                  frames: Optional[Sequence[int]] = None, flags: int = 0, want_source: bool = False):
+                  frames: Optional[Sequence[int]] = None, flags: int = 0, want_source: bool = False, finalize: bool = True):
         """speech_feat (B, 80, Fmax) -> (wav (B, 480*Fmax), source (B, 1, 480*Fmax) or None).
-        Samples past 480*frames[b] of a shorter utterance are left untouched (zeros)."""
+        Samples past 480*frames[b] of a shorter utterance are left untouched (zeros).
+        finalize=False (generator.py:713-726, a streaming chunk): 3 + 4 frames are look-ahead and one frame of samples is held
+        back: utterance b is valid in wav[b, :480*(frames[b] - 8)], its source in [:480*(frames[b] - 3)]."""
+        if not finalize:
+            flags |= FY_NO_FINALIZE
         mel, B, Fmax, fr = self._prep(speech_feat, frames)
         S = Fmax * self.cfg.upsample_total
         assert sine_noise.is_cuda and sine_noise.is_contiguous() and sine_noise.shape[-2] >= S

@@ -43,6 +43,8 @@ int fy_prof_get(const char* name, double* total_ms, double* work, int64_t* count
 #define FY_PRECISE 1u /* split-bf16 (hi+lo) activations on the MFMA paths: fp32-class accuracy, 2x MFMA work */
 #define FY_DIRECT 2u  /* HiFT / DiT position conv: run convolutions on the exact fp32 VALU kernel */
 #define FY_STREAMING 4u /* flow: block-causal chunk attention mask (streaming=True in the reference) */
+#define FY_NO_FINALIZE 8u /* flow, HiFT: a streaming chunk (finalize=False in the reference): the last tokens / frames are
+                            look-ahead context, not output (flow: pre_lookahead tokens; HiFT: 3 + 4 frames and 480 samples) */
 
 /* ================================ HiFT vocoder ================================
  * replaces CausalHiFTGenerator.inference(speech_feat, finalize=True)

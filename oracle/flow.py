@@ -35,11 +35,16 @@ def prepare(sd: Dict[str, np.ndarray]) -> Params:
 
 # ---- pieces outside the estimator ------------------------------------------
 
-def prelookahead(x, P: Params, cfg: FlowCfg):
-    """PreLookaheadLayer.forward (no context), transformer/upsample_encoder.py:82-103.
-    x (B, N, 80) -> (B, N, 80)."""
+def prelookahead(x, P: Params, cfg: FlowCfg, context=None):
+    """PreLookaheadLayer.forward, transformer/upsample_encoder.py:82-103.
+    x (B, N, 80) -> (B, N, 80); `context` (B, pre_lookahead, 80) replaces the zero
+    look-ahead of a streaming chunk."""
     h = x.transpose(1, 2)
-    h = F.pad(h, (0, cfg.pre_lookahead))
+    if context is None:
+        h = F.pad(h, (0, cfg.pre_lookahead))
+    else:
+        assert context.shape[1] == cfg.pre_lookahead
+        h = torch.cat([h, context.transpose(1, 2)], dim=2)
     h = F.leaky_relu(F.conv1d(h, P["pre_lookahead_layer.conv1.weight"], P["pre_lookahead_layer.conv1.bias"]))
     h = F.pad(h, (2, 0))
     h = F.conv1d(h, P["pre_lookahead_layer.conv2.weight"], P["pre_lookahead_layer.conv2.bias"])
@@ -200,14 +205,17 @@ def solve_euler(z, mu, mask, spks, cond, P: Params, cfg: FlowCfg, streaming: boo
     return x.float()
 
 
-def flow_front(token, prompt_token, prompt_feat, embedding, P: Params, cfg: FlowCfg):
+def flow_front(token, prompt_token, prompt_feat, embedding, P: Params, cfg: FlowCfg, finalize: bool = True):
     """flow.py:370-390: everything before the CFM solver.
     Returns mu (1, 80, T), spks (1, 80), cond (1, 80, T), P_mel."""
     emb = F.normalize(embedding, dim=1)
     spks = F.linear(emb, P["spk_embed_affine_layer.weight"], P["spk_embed_affine_layer.bias"])
     tok = torch.cat([prompt_token, token], dim=1).long()
     h = F.embedding(torch.clamp(tok, min=0), P["input_embedding.weight"])      # mask is all ones for B=1
-    h = prelookahead(h, P, cfg)
+    if finalize:
+        h = prelookahead(h, P, cfg)
+    else:                                                                      # flow.py:382-383
+        h = prelookahead(h[:, :-cfg.pre_lookahead], P, cfg, context=h[:, -cfg.pre_lookahead:])
     h = h.repeat_interleave(2, dim=1)
     p_mel = prompt_feat.shape[1]
     T = h.shape[1]
@@ -217,12 +225,13 @@ def flow_front(token, prompt_token, prompt_feat, embedding, P: Params, cfg: Flow
 
 
 def inference(token, prompt_token, prompt_feat, embedding, P: Params, cfg: FlowCfg, rand_noise,
-              streaming: bool = False):
-    """CausalMaskedDiffWithDiT.inference (finalize=True), flow/flow.py:358-403.
+              streaming: bool = False, finalize: bool = True):
+    """CausalMaskedDiffWithDiT.inference, flow/flow.py:358-403.
     token (1, n) int, prompt_token (1, P_tok) int, prompt_feat (1, P_mel, 80),
-    embedding (1, 192), rand_noise (1, 80, >=T) -> mel (1, 80, 2n)."""
+    embedding (1, 192), rand_noise (1, 80, >=T) -> mel (1, 80, 2n), or
+    (1, 80, 2(n - pre_lookahead)) with finalize=False."""
     with torch.no_grad():
-        mu, spks, cond, p_mel = flow_front(token, prompt_token, prompt_feat, embedding, P, cfg)
+        mu, spks, cond, p_mel = flow_front(token, prompt_token, prompt_feat, embedding, P, cfg, finalize)
         T = mu.shape[2]
         mask = torch.ones(1, 1, T)
         z = rand_noise[:, :, :T]

@@ -47,12 +47,21 @@ def prepare(sd: Dict[str, np.ndarray]) -> Params:
 
 # ---- building blocks --------------------------------------------------------
 
-def causal_conv1d(x, w, b, dilation: int = 1, causal: str = "left"):
-    """CausalConv1d.forward, transformer/convolution.py:176-187: (k-1)*d zeros on
-    the left ('left') or on the right ('right'), then a plain stride-1 conv."""
+def causal_padding(w, dilation: int = 1) -> int:
     k = w.shape[-1]
-    pad = int((k * dilation - dilation) / 2) * 2 + (k + 1) % 2     # convolution.py:172
-    x = F.pad(x, (pad, 0) if causal == "left" else (0, pad))
+    return int((k * dilation - dilation) / 2) * 2 + (k + 1) % 2    # convolution.py:172
+
+
+def causal_conv1d(x, w, b, dilation: int = 1, causal: str = "left", cache=None):
+    """CausalConv1d.forward, transformer/convolution.py:176-187: (k-1)*d zeros (or
+    `cache`, the streaming look-ahead / history) on the left ('left') or on the
+    right ('right'), then a plain stride-1 conv."""
+    pad = causal_padding(w, dilation)
+    if cache is None:
+        x = F.pad(x, (pad, 0) if causal == "left" else (0, pad))
+    else:
+        assert cache.shape[2] == pad
+        x = torch.cat([cache, x], dim=2) if causal == "left" else torch.cat([x, cache], dim=2)
     y = F.conv1d(x, w, b, dilation=dilation)
     return y
 
@@ -88,11 +97,18 @@ def resblock(x, P: Params, prefix: str, dilations=(1, 3, 5)):
 
 # ---- f0 predictor -----------------------------------------------------------
 
-def f0_predictor(mel, P: Params):
-    """CausalConvRNNF0Predictor.forward (finalize=True), f0_predictor.py:95-103.
-    mel (B, 80, F) -> f0 (B, F).  First conv looks 3 frames right, the other
-    four are left-causal; ELU after each; |Linear(512->1)|."""
-    x = causal_conv1d(mel, P["f0_predictor.condnet.0.weight"], P["f0_predictor.condnet.0.bias"], causal="right")
+def f0_predictor(mel, P: Params, finalize: bool = True):
+    """CausalConvRNNF0Predictor.forward, f0_predictor.py:95-103.
+    mel (B, 80, F) -> f0 (B, F) (finalize) or (B, F - 3) (streaming chunk: the
+    last 3 frames are the first conv's look-ahead instead of zeros).  First conv
+    looks 3 frames right, the other four are left-causal; ELU after each;
+    |Linear(512->1)|."""
+    w0 = P["f0_predictor.condnet.0.weight"]
+    if finalize:
+        x = causal_conv1d(mel, w0, P["f0_predictor.condnet.0.bias"], causal="right")
+    else:
+        pad = causal_padding(w0)
+        x = causal_conv1d(mel[:, :, :-pad], w0, P["f0_predictor.condnet.0.bias"], causal="right", cache=mel[:, :, -pad:])
     x = F.elu(x)
     for i in (2, 4, 6, 8):
         x = F.elu(causal_conv1d(x, P[f"f0_predictor.condnet.{i}.weight"], P[f"f0_predictor.condnet.{i}.bias"]))
@@ -182,13 +198,23 @@ def istft(mag, phase, cfg: HiftCfg) -> torch.Tensor:
 
 # ---- decoder ----------------------------------------------------------------
 
-def decode_taps(mel, s, P: Params, cfg: HiftCfg) -> Dict[str, torch.Tensor]:
-    """CausalHiFTGenerator.decode (finalize=True), generator.py:672-711, keeping
-    the per-stage tensors the golden fixtures tap."""
+def decode_taps(mel, s, P: Params, cfg: HiftCfg, finalize: bool = True) -> Dict[str, torch.Tensor]:
+    """CausalHiFTGenerator.decode, generator.py:672-711, keeping the per-stage
+    tensors the golden fixtures tap.  finalize=False (a streaming chunk, :674-679,
+    :708-709): the last `pre_look_right` mel frames are conv_pre's look-ahead, the
+    source STFT is trimmed to match and the last 480 samples are held back."""
     taps: Dict[str, torch.Tensor] = {}
     s_stft = stft(s.squeeze(1), cfg)
+    up_total = 1
+    for u in cfg.ups:
+        up_total *= u
+    if finalize:
+        x = causal_conv1d(mel, P["conv_pre.weight"], P["conv_pre.bias"], causal="right")
+    else:
+        r = cfg.pre_look_right
+        x = causal_conv1d(mel[:, :, :-r], P["conv_pre.weight"], P["conv_pre.bias"], causal="right", cache=mel[:, :, -r:])
+        s_stft = s_stft[:, :, :-up_total * r]
     taps["s_stft"] = s_stft
-    x = causal_conv1d(mel, P["conv_pre.weight"], P["conv_pre.bias"], causal="right")
     taps["conv_pre"] = x
     n_up, n_k = len(cfg.ups), len(cfg.rb_k)
     for i in range(n_up):
@@ -217,18 +243,25 @@ def decode_taps(mel, s, P: Params, cfg: HiftCfg) -> Dict[str, torch.Tensor]:
     mag = torch.exp(x[:, :half])
     ph = torch.sin(x[:, half:])
     y = istft(mag, ph, cfg)
+    if not finalize:
+        y = y[:, :-up_total * cfg.hop]
     taps["wav"] = torch.clamp(y, -cfg.audio_limit, cfg.audio_limit)
     return taps
 
 
-def decode(mel, s, P: Params, cfg: HiftCfg) -> torch.Tensor:
-    return decode_taps(mel, s, P, cfg)["wav"]
+def decode(mel, s, P: Params, cfg: HiftCfg, finalize: bool = True) -> torch.Tensor:
+    return decode_taps(mel, s, P, cfg, finalize)["wav"]
 
 
-def inference(mel, P: Params, cfg: HiftCfg, rand_ini, sine_noise) -> Tuple[torch.Tensor, torch.Tensor]:
-    """CausalHiFTGenerator.inference (finalize=True), generator.py:713-726.
-    mel (B, 80, F) -> (wav (B, 480 F), source (B, 1, 480 F))."""
+def inference(mel, P: Params, cfg: HiftCfg, rand_ini, sine_noise, finalize: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """CausalHiFTGenerator.inference, generator.py:713-726.
+    mel (B, 80, F) -> (wav (B, 480 F), source (B, 1, 480 F)); with finalize=False
+    (B, 480 (F - 8)) and (B, 1, 480 (F - 3)): 3 frames of f0 look-ahead, 4 of
+    conv_pre look-ahead, one frame of samples held back."""
     with torch.no_grad():
-        f0 = f0_predictor(mel, P)
+        f0 = f0_predictor(mel, P, finalize)
         s = sine_source(f0, P, cfg, rand_ini, sine_noise)
-        return decode(mel, s, P, cfg), s
+        if finalize:
+            return decode(mel, s, P, cfg, True), s
+        pad = causal_padding(P["f0_predictor.condnet.0.weight"])
+        return decode(mel[:, :, :-pad], s, P, cfg, False), s

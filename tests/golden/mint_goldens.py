@@ -379,9 +379,69 @@ def mint_e2e(tag, cfg: ModelCfg, cases, out):
     np.savez_compressed(os.path.join(out, f"e2e_{tag}.npz"), **fx)
 
 
+def mint_stream(tag, cfg: ModelCfg, hift_frames, flow_case, e2e_cases, out):
+    """The streaming forms: CausalHiFTGenerator.inference(finalize=False), CausalMaskedDiffWithDiT.inference(streaming=True,
+    finalize=False) and CosyVoice3Model.tts(stream=True) (chunk by chunk)."""
+    from cosyvoice.cli.model import CosyVoice3Model
+    llm, flow, hift = build_llm(cfg.llm), build_flow(cfg.flow), build_hift(cfg.hift)
+    fx = {}
+    with torch.inference_mode():
+        for Fr in hift_frames:
+            set_hift_noise(hift, Fr * cfg.hift.upsample_total)
+            mel = torch.from_numpy(synth.uniform(f"in.hift.mel.{Fr}", (1, 80, Fr), 0.0, 1.0))
+            wav, s = hift.inference(mel, finalize=False)
+            print(f"[stream {tag}] hift F={Fr} finalize=False: wav {tuple(wav.shape)} source {tuple(s.shape)}")
+            fx.update(pack(f"hift.F{Fr}.wav", digest(wav)))
+            fx.update(pack(f"hift.F{Fr}.source", digest(s)))
+            if Fr <= 30:
+                fx[f"hift.F{Fr}.wav_full"] = wav.numpy().astype(np.float32)
+        n, p_tok = flow_case
+        token = torch.from_numpy(synth.randint(f"in.flow.token.{n}", (1, n), 0, cfg.flow.vocab))
+        ptoken = torch.from_numpy(synth.randint(f"in.flow.ptoken.{p_tok}", (1, p_tok), 0, cfg.flow.vocab))
+        pfeat = torch.from_numpy(synth_mel(f"in.flow.pfeat.{p_tok}", 2 * p_tok))
+        emb = torch.from_numpy(synth.normal("in.flow.spk", (1, cfg.flow.spk_in)))
+        flow.decoder.rand_noise = torch.from_numpy(synth.flow_rand_noise(2 * (n + p_tok)))
+        mel, _ = flow.inference(token, torch.tensor([n]), ptoken, torch.tensor([p_tok]), pfeat, torch.tensor([2 * p_tok]), emb,
+                                streaming=True, finalize=False)
+        print(f"[stream {tag}] flow n={n} P={p_tok} streaming, finalize=False: mel {tuple(mel.shape)}")
+        fx.update(pack(f"flow.{n}_{p_tok}", digest(mel)))
+        if mel.numel() <= 8000:
+            fx[f"flow.{n}_{p_tok}.full"] = mel.numpy()
+    model = CosyVoice3Model(llm, flow, hift)
+    for (n_text, n_ptext, p_llm, p_flow) in e2e_cases:
+        ctag = f"{n_text}_{n_ptext}_{p_llm}_{p_flow}"
+        text, ptext, ptok_llm = llm_case(cfg.llm, n_text, n_ptext, p_llm, ctag)
+        ptok_flow = torch.from_numpy(synth.randint(f"in.flow.ptoken.{p_flow}", (1, p_flow), 0, cfg.flow.vocab))
+        pfeat = torch.from_numpy(synth_mel(f"in.flow.pfeat.{p_flow}", 2 * p_flow))
+        emb = torch.from_numpy(synth.normal("in.flow.spk", (1, cfg.flow.spk_in)))
+        flow.decoder.rand_noise = torch.from_numpy(synth.flow_rand_noise(2 * (p_flow + 20 * n_text)))
+        set_hift_noise(hift, 2 * 20 * n_text * 480)
+        toks_seen = {}
+        orig_job = model.llm_job
+
+        def job(text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid):
+            orig_job(text, prompt_text, llm_prompt_speech_token, llm_embedding, uuid)
+            toks_seen["t"] = list(model.tts_speech_token_dict[uuid])
+        model.llm_job = job
+        t0 = time.time()
+        outs = [o["tts_speech"] for o in model.tts(text=text, flow_embedding=emb, llm_embedding=emb, prompt_text=ptext,
+                                                   llm_prompt_speech_token=ptok_llm, flow_prompt_speech_token=ptok_flow,
+                                                   prompt_speech_feat=pfeat, stream=True)]
+        model.llm_job = orig_job
+        toks = toks_seen["t"]
+        print(f"[stream {tag}] tts(stream=True) case {ctag}: {len(toks)} tokens -> chunks {[o.shape[1] for o in outs]} "
+              f"in {time.time() - t0:.1f}s")
+        fx[f"e2e.c{ctag}.tokens"] = np.asarray(toks, dtype=np.int32)
+        fx[f"e2e.c{ctag}.chunk_samples"] = np.asarray([o.shape[1] for o in outs], dtype=np.int64)
+        for i, o in enumerate(outs):
+            fx.update(pack(f"e2e.c{ctag}.chunk{i}", digest(o)))
+        fx.update(pack(f"e2e.c{ctag}.wav", digest(torch.cat(outs, dim=1))))
+    np.savez_compressed(os.path.join(out, f"stream_{tag}.npz"), **fx)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="hift,flow,llm,e2e")
+    ap.add_argument("--only", default="hift,flow,llm,e2e,stream")
     ap.add_argument("--full", action="store_true", help="also mint the full-size (CosyVoice3-0.5B shape) fixtures")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
@@ -405,6 +465,10 @@ def main():
         mint_e2e("tiny", tiny, [(8, 6, 0, 12), (6, 5, 20, 20)], a.out)
         if a.full:
             mint_e2e("full", ModelCfg(), [(8, 8, 0, 25)], a.out)
+    if "stream" in only:
+        mint_stream("tiny", tiny, [30], (31, 10), [(40, 6, 0, 12)], a.out)
+        if a.full:
+            mint_stream("full", ModelCfg(), [30], (23, 10), [(8, 8, 0, 25)], a.out)
 
 
 if __name__ == "__main__":

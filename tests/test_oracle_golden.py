@@ -226,3 +226,46 @@ def test_tts_against_reference():
         assert out["tokens"][0].tolist() == f[f"c{ctag}.tokens"].tolist()
         check(out["mel"], f, f"c{ctag}.mel", RT, 1e-4)
         check(out["tts_speech"], f, f"c{ctag}.wav", 1e-3, 1e-4)
+
+
+# ------------------------------------------------------------------ streaming forms
+
+def test_stream_against_reference():
+    """finalize=False vocoder / flow chunk and CosyVoice3Model.tts(stream=True), chunk by chunk."""
+    f = fx("stream_tiny.npz")
+    cfg = ModelCfg.tiny()
+    PL = ollm.prepare(synth.state_dict(cfg.llm.manifest()))
+    PF = oflow.prepare(synth.state_dict(cfg.flow.manifest()))
+    PH = ohift.prepare(synth.state_dict(cfg.hift.manifest()))
+    ri = torch.from_numpy(synth.hift_rand_ini())
+    Fr = 30
+    mel = torch.from_numpy(synth.uniform(f"in.hift.mel.{Fr}", (1, 80, Fr), 0.0, 1.0))
+    wav, s = ohift.inference(mel, PH, cfg.hift, ri, torch.from_numpy(synth.hift_sine_noise(Fr * 480)), finalize=False)
+    assert wav.shape == (1, (Fr - 8) * 480) and s.shape == (1, 1, (Fr - 3) * 480)
+    check(s, f, f"hift.F{Fr}.source", 1e-3, 1e-4)
+    np.testing.assert_allclose(wav.numpy(), f[f"hift.F{Fr}.wav_full"], rtol=1e-3, atol=1e-4)
+    n, p_tok = 31, 10
+    token = torch.from_numpy(synth.randint(f"in.flow.token.{n}", (1, n), 0, cfg.flow.vocab))
+    ptoken = torch.from_numpy(synth.randint(f"in.flow.ptoken.{p_tok}", (1, p_tok), 0, cfg.flow.vocab))
+    pfeat = torch.from_numpy(synth_mel(f"in.flow.pfeat.{p_tok}", 2 * p_tok))
+    emb = torch.from_numpy(synth.normal("in.flow.spk", (1, cfg.flow.spk_in)))
+    m = oflow.inference(token, ptoken, pfeat, emb, PF, cfg.flow, torch.from_numpy(synth.flow_rand_noise(2 * (n + p_tok))),
+                        streaming=True, finalize=False)
+    assert m.shape == (1, 80, 2 * (n - cfg.flow.pre_lookahead))
+    check(m, f, f"flow.{n}_{p_tok}", RT, 1e-4)
+    n_text, n_ptext, p_llm, p_flow = 40, 6, 0, 12
+    ctag = f"{n_text}_{n_ptext}_{p_llm}_{p_flow}"
+    text, ptext, ptok = llm_case(cfg.llm, n_text, n_ptext, p_llm, ctag)
+    inp = {
+        "text": text, "prompt_text": ptext, "llm_prompt_speech_token": ptok,
+        "flow_prompt_speech_token": torch.from_numpy(synth.randint(f"in.flow.ptoken.{p_flow}", (1, p_flow), 0, 6561)),
+        "prompt_speech_feat": torch.from_numpy(synth_mel(f"in.flow.pfeat.{p_flow}", 2 * p_flow)),
+        "flow_embedding": torch.from_numpy(synth.normal("in.flow.spk", (1, 192))),
+    }
+    out = opipe.tts_stream(inp, PL, PF, PH, cfg, torch.from_numpy(synth.flow_rand_noise(2 * (p_flow + 20 * n_text))), ri,
+                           torch.from_numpy(synth.hift_sine_noise(2 * 20 * n_text * 480)))
+    assert out["tokens"][0].tolist() == f[f"e2e.c{ctag}.tokens"].tolist()
+    assert [c.shape[1] for c in out["chunks"]] == f[f"e2e.c{ctag}.chunk_samples"].tolist()
+    for i, c in enumerate(out["chunks"]):
+        check(c, f, f"e2e.c{ctag}.chunk{i}", 1e-3, 1e-4)
+    check(out["tts_speech"], f, f"e2e.c{ctag}.wav", 1e-3, 1e-4)

@@ -1,0 +1,126 @@
+"""GPU parity of the streaming forms: HiFT / flow with finalize=False and CosyVoice3Model.tts(stream=True),
+against the fixtures minted from the reference (tests/golden/stream_*.npz) and the oracle.
+
+Tolerances as for the non-streaming forms (tests/test_hift_gpu.py, test_flow_gpu.py, test_e2e_gpu.py): HiFT fp32 mode 2e-3 on
+the waveform against the reference fixture, default bf16 mode 1.5e-2; flow mel max |err| <= 6e-2; streamed tokens and chunk
+lengths exact; every chunk's samples within 1.5e-2 of the oracle vocoder run on the engine's own mel (the NSF source
+integrates f0, so a comparison through a differently rounded mel decorrelates - see test_e2e_gpu.py); the first 10
+frames of the stream within 3e-2 of the reference fixture itself.
+"""
+import numpy as np
+import pytest
+import torch
+
+from _digest import check
+from fangyan_tts_amd import synth
+from fangyan_tts_amd.spec import FlowCfg, HiftCfg, ModelCfg
+from gpu_util import golden, llm_case, maxerr, note, synth_mel
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("tag", ["tiny", "full"])
+def test_hift_chunk(tag):
+    from fangyan_tts_amd.hift import HiftEngine
+    f = golden(f"stream_{tag}.npz")
+    if f is None:
+        pytest.skip(f"stream_{tag}.npz not minted")
+    cfg = ModelCfg.tiny().hift if tag == "tiny" else HiftCfg()
+    sd = synth.state_dict_torch(cfg.manifest(), DEV)
+    eng = HiftEngine(sd, cfg, max_batch=2, max_frames=40, device=DEV)
+    Fr = 30
+    mel = torch.from_numpy(synth.uniform(f"in.hift.mel.{Fr}", (1, 80, Fr), 0.0, 1.0)).to(DEV)
+    ri = torch.from_numpy(synth.hift_rand_ini()).to(DEV)
+    sn = torch.from_numpy(synth.hift_sine_noise(40 * 480)).to(DEV)
+    for mode, flags, tol in (("direct", 2, 2e-3), ("bf16", 0, 1.5e-2)):
+        wav, src = eng.inference(mel, ri, sn, flags=flags, want_source=True, finalize=False)
+        n = (Fr - 8) * 480
+        e = float(np.abs(wav[0, :n].cpu().numpy() - f[f"hift.F{Fr}.wav_full"][0]).max())
+        note("parity_stream.json", f"hift.{tag}.{mode}.wav_maxerr", e)
+        assert e < tol
+        assert float(wav[0, n:].abs().max()) == 0.0                      # the held-back frame is not written
+        if flags == 2:
+            check(src[:, :, : (Fr - 3) * 480].cpu(), f, f"hift.F{Fr}.source", 1e-3, 5e-3)
+    # ragged batch: a chunk beside a longer one equals the chunk alone
+    mel2 = torch.zeros(2, 80, 38, device=DEV)
+    mel2[0, :, :Fr] = mel[0]
+    mel2[1] = torch.from_numpy(synth.uniform("in.hift.mel.38", (1, 80, 38), 0.0, 1.0)).to(DEV)[0]
+    w2, _ = eng.inference(mel2, ri, sn, frames=[Fr, 38], finalize=False)
+    w1, _ = eng.inference(mel, ri, sn, finalize=False)
+    assert torch.equal(w2[0, : (Fr - 8) * 480], w1[0, : (Fr - 8) * 480])
+
+
+@pytest.mark.parametrize("tag,n,p_tok", [("tiny", 31, 10), ("full", 23, 10)])
+def test_flow_chunk(tag, n, p_tok):
+    from fangyan_tts_amd.flow import FlowEngine
+    f = golden(f"stream_{tag}.npz")
+    if f is None:
+        pytest.skip(f"stream_{tag}.npz not minted")
+    cfg = ModelCfg.tiny().flow if tag == "tiny" else FlowCfg()
+    sd = synth.state_dict_torch(cfg.manifest(), DEV)
+    eng = FlowEngine(sd, cfg, max_batch=1, max_frames=2 * (n + p_tok), device=DEV)
+    token = torch.from_numpy(synth.randint(f"in.flow.token.{n}", (1, n), 0, cfg.vocab))
+    ptoken = torch.from_numpy(synth.randint(f"in.flow.ptoken.{p_tok}", (1, p_tok), 0, cfg.vocab))
+    pfeat = torch.from_numpy(synth_mel(f"in.flow.pfeat.{p_tok}", 2 * p_tok))
+    emb = torch.from_numpy(synth.normal("in.flow.spk", (1, cfg.spk_in)))
+    noise = torch.from_numpy(synth.flow_rand_noise(2 * (n + p_tok)))
+    mel = eng.inference(token, [n], ptoken, [p_tok], pfeat, [2 * p_tok], emb, noise, streaming=True, finalize=False)
+    valid = 2 * (n - cfg.pre_lookahead)
+    assert float(mel[:, :, valid:].abs().max()) == 0.0
+    check(mel[:, :, :valid].cpu(), f, f"flow.{n}_{p_tok}", 5e-2, 6e-2)
+
+
+@pytest.mark.parametrize("tag,case", [("tiny", (40, 6, 0, 12)), ("full", (8, 8, 0, 25))])
+def test_tts_stream_against_reference(tag, case):
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    from oracle import hift as ohift
+    f = golden(f"stream_{tag}.npz")
+    if f is None:
+        pytest.skip(f"stream_{tag}.npz not minted")
+    cfg = ModelCfg.tiny() if tag == "tiny" else ModelCfg()
+    n_text, n_ptext, p_llm, p_flow = case
+    ctag = f"{n_text}_{n_ptext}_{p_llm}_{p_flow}"
+    sd = [synth.state_dict_torch(m.manifest(), DEV, skip=("lm_head",)) for m in (cfg.llm, cfg.flow, cfg.hift)]
+    ri = torch.from_numpy(synth.hift_rand_ini())
+    sn = torch.from_numpy(synth.hift_sine_noise(2 * 20 * n_text * 480))
+    m = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, device=DEV, max_batch=1, max_text=64, max_prompt_tokens=32, max_tokens=20 * n_text,
+                        rand_noise=torch.from_numpy(synth.flow_rand_noise(2 * (p_flow + 20 * n_text))), rand_ini=ri, sine_noise=sn)
+    t, pt, pk = llm_case(cfg.llm, n_text, n_ptext, p_llm, ctag)
+    inp = {
+        "text": torch.tensor([t], dtype=torch.int32), "prompt_text": torch.tensor([pt], dtype=torch.int32),
+        "llm_prompt_speech_token": torch.tensor([pk], dtype=torch.int32).reshape(1, -1),
+        "flow_prompt_speech_token": torch.from_numpy(synth.randint(f"in.flow.ptoken.{p_flow}", (1, p_flow), 0, 6561)),
+        "prompt_speech_feat": torch.from_numpy(synth_mel(f"in.flow.pfeat.{p_flow}", 2 * p_flow)),
+        "flow_embedding": torch.from_numpy(synth.normal("in.flow.spk", (1, 192))),
+    }
+    chunks = [o["tts_speech"] for o in m.tts(**inp, stream=True)]
+    assert [c.shape[1] for c in chunks] == f[f"e2e.c{ctag}.chunk_samples"].tolist()
+    assert all(c.device.type == "cpu" and c.shape[0] == 1 for c in chunks)
+    # the token sequence behind the chunks: the reference's greedy ids (the chunk lengths above already depend on its length)
+    wav_ns, samples, toks = m.tts_batch([inp])
+    assert toks[0].cpu().tolist() == f[f"e2e.c{ctag}.tokens"].tolist()
+    # every chunk against the oracle vocoder on the engine's own accumulated mel
+    P = ohift.prepare({k: v.cpu().numpy() for k, v in sd[2].items()})
+    gen = m.tts(**inp, stream=True)
+    list(gen)
+    mel_all = m.last_mel.cpu()
+    first = f[f"e2e.c{ctag}.chunk_samples"].tolist()
+    off, worst = 0, 0.0
+    for i, c in enumerate(chunks):
+        last = i == len(chunks) - 1
+        end = off + c.shape[1]
+        Fk = end // 480 + (0 if last else 8)
+        ref, _ = ohift.inference(mel_all[:, :, :Fk], P, cfg.hift, ri, sn, finalize=last)
+        worst = max(worst, maxerr(c, ref[:, off:end]))
+        off = end
+    note("parity_stream.json", f"tts_stream.{tag}.chunk_wav_vs_oracle_vocoder_on_engine_mel", worst)
+    assert worst < 1.5e-2
+    # and the first 10 frames of the stream against the reference fixture itself
+    from _digest import sample_idx
+    si = sample_idx(first[0])
+    early = si < 4800
+    got = chunks[0][0].numpy()[si][early]
+    want = f[f"e2e.c{ctag}.chunk0.samples"][early]
+    note("parity_stream.json", f"tts_stream.{tag}.first10frames_maxerr", float(np.abs(got - want).max()))
+    assert np.abs(got - want).max() < 3e-2          # measured 1.9e-2 (full size), 1.9e-3 (reduced size)
