@@ -72,6 +72,7 @@ def _declare(L):
     L.fy_prof_enable.restype = None
     L.fy_prof_reset.restype = None
     L.fy_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.fy_llm_set_sampler.argtypes = [vp, i32, f32p, C.c_int64, i32, C.c_float, i32, C.c_float]
     L.fy_hift_default_config.argtypes = [C.POINTER(HiftConfig)]
     L.fy_hift_default_config.restype = None
     L.fy_hift_create.argtypes = [C.POINTER(vp), C.POINTER(HiftConfig), C.POINTER(FyTensor), i32, i32, i32, vp]

@@ -98,7 +98,7 @@ class _MissingFrontEnd:
 
 class CosyVoice3:
     def __init__(self, model_dir, load_trt=False, load_vllm=False, fp16=False, trt_concurrent=1, frontend=None,
-                 max_batch: int = 1, max_tokens: int = 1500, max_prompt_tokens: int = 750, device=None):
+                 max_batch: int = 1, max_tokens: int = 1500, max_prompt_tokens: int = 750, device=None, sampler: str = "ras"):
         self.model_dir, self.fp16 = model_dir, fp16
         if not os.path.exists(model_dir):
             raise ValueError("{} not found (no network here: the reference would call snapshot_download)".format(model_dir))
@@ -117,7 +117,8 @@ class CosyVoice3:
         dev = device or torch.device("cuda", torch.cuda.current_device())
         to_dev = lambda sd: {k: v.to(dev, torch.float32).contiguous() for k, v in sd.items() if "lm_head" not in k}
         self.model = CosyVoice3Model(to_dev(sds[0]), to_dev(sds[1]), to_dev(sds[2]), self.cfg, device=dev, max_batch=max_batch,
-                                     max_tokens=max_tokens, max_prompt_tokens=max_prompt_tokens, fp16=fp16, keep_llm_weights=True)
+                                     max_tokens=max_tokens, max_prompt_tokens=max_prompt_tokens, fp16=fp16, keep_llm_weights=True,
+                                     sampler=sampler)
 
     # ---- speaker bookkeeping (cli/cosyvoice.py:64-78) ------------------------------------------------
     def list_available_spks(self):

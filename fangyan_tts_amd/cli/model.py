@@ -23,7 +23,8 @@ class CosyVoice3Model:
                  hift_weights: Dict[str, torch.Tensor], cfg: ModelCfg = ModelCfg(), device: Optional[torch.device] = None,
                  max_batch: int = 8, max_text: int = 128, max_prompt_tokens: int = 800, max_tokens: int = 800,
                  rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
-                 sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False, n_llm: int = 1):
+                 sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False, n_llm: int = 1,
+                 sampler: str = "greedy", sampler_seed: int = 1986):
         if not torch.cuda.is_available():
             raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -46,6 +47,17 @@ class CosyVoice3Model:
         self.sine_noise = (sine_noise if sine_noise is not None else torch.rand(1, n, 9, generator=g)).to(self.device).contiguous()
         self.token_hop_len = 25
         self.lock = threading.Lock()          # the engines' handles are single-threaded
+        # "greedy": the deterministic rule of SURVEY 8 a4.  "ras": the reference's default repetition-aware sampling; its
+        # multinomial draws come from fresh uniforms (one row per sequence slot) drawn before every LM call
+        self.sampler = sampler
+        self._sampler_gen = torch.Generator(device=self.device).manual_seed(sampler_seed)
+        self._uniforms = [torch.zeros(max_batch, 4 * max_tokens + 256, device=self.device) for _ in self.llms] if sampler == "ras" else None
+        assert sampler in ("greedy", "ras")
+
+    def _arm_sampler(self, i: int = 0):
+        if self.sampler == "ras":
+            self._uniforms[i].uniform_(0.0, 1.0, generator=self._sampler_gen)
+            self.llms[i].set_sampler("ras", self._uniforms[i])
 
     # ------------------------------------------------------------------ batched path
     @torch.inference_mode()
@@ -60,6 +72,7 @@ class CosyVoice3Model:
         ptext = [d.get("prompt_text", z).reshape(-1).tolist() for d in inputs]
         pspeech = [d.get("llm_prompt_speech_token", z).reshape(-1).tolist() for d in inputs]
         with self.lock:
+            self._arm_sampler()
             out, out_n, _ = self.llm.generate(text, ptext, pspeech, min_len=min_len, max_len=max_len)
             n_tok = out_n.cpu().tolist()
             if min(n_tok) < 1:
@@ -102,6 +115,7 @@ class CosyVoice3Model:
                         pspeech = [d.get("llm_prompt_speech_token", z).reshape(-1).tolist() for d in inputs]
                         mn = min_len[bi] if min_len is not None else None
                         mx = max_len[bi] if max_len is not None else None
+                        self._arm_sampler(pi)
                         out, out_n, _ = llm.generate(text, ptext, pspeech, min_len=mn, max_len=mx)
                         n_tok = out_n.cpu().tolist()              # synchronises the LM stream: the ids are complete
                         q.put((inputs, out, n_tok))
@@ -189,6 +203,7 @@ class CosyVoice3Model:
         look, hop0 = self.cfg.flow.pre_lookahead, self.token_hop_len
         up = self.cfg.hift.upsample_total
         with self.lock:
+            self._arm_sampler()
             out, out_n, _ = self.llm.generate(text, ptext, pspeech)
             n = int(out_n.cpu()[0])
             if n < 1:

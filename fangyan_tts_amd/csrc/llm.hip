@@ -30,7 +30,13 @@ struct fy_llm {
     float *h, *xn, *qkv, *ao, *act, *hb, *logits, *partial, *logp_keep;
     bf16_t* act_split = nullptr;                     // SwiGLU output as three bf16 planes per 8 rows: [rows/8][24][inter]
     int *row_seq, *row_pos, *row_src, *last_row;
-    int *st;                                          // [8][max_batch]: pos, raw_n, n_out, done, run, min_len, max_len, (spare)
+    int *st;                                          // [8][max_batch]: pos, raw_n, n_out, done (2 = sampler gave up), run, min_len, max_len, uniforms used
+    // sampler (fy_llm_set_sampler): 0 greedy, 1 repetition-aware sampling from caller-supplied uniforms
+    int sampler = 0, top_k = 25, win_size = 10;
+    float top_p = 0.8f, rep_thr = 1.0f;
+    const float* uniforms = nullptr;                  // device (max_batch, n_uniforms), borrowed
+    long n_uniforms = 0;
+    int* recent = nullptr;                            // [win_size][max_batch] last raw tokens (ring)
     int *seq_ids;                                     // 0..max_batch-1
     int *counters = nullptr;                          // split-K arrival counters of the down projection
     int B = 0;
@@ -174,6 +180,201 @@ __global__ __launch_bounds__(256) void sample_k(const float* __restrict__ logits
     }
 }
 
+// ---- repetition-aware sampling (ras_sampling / nucleus_sampling / random_sampling, utils/common.py:137-166,
+// and the ignore_eos retry loop of TransformerLM.sampling_ids, llm/llm.py:149-164) ---------------------------------------
+// torch.multinomial(1) draws from torch's global generator, which no other implementation can follow; the draw is
+// therefore DEFINED here (and identically in oracle/llm.py:inv_cdf and in the fixture mint, which patches
+// Tensor.multinomial) as the inverse CDF at a caller-supplied uniform u in [0, 1): weights are summed in double, in index
+// order, in chunks of ceil(n/256) (chunk sums, then a running sum over chunks, then a running sum inside the chosen
+// chunk started from the previous chunks' total); the sample is the first index whose running sum exceeds u x total.
+__device__ int inv_cdf_small(const float* p, int n, float u) {
+    double tot = 0.0;
+    for (int j = 0; j < n; ++j) tot += (double)p[j];
+    const double target = (double)u * tot;
+    double c = 0.0;
+    for (int j = 0; j < n; ++j) {
+        c += (double)p[j];
+        if (c > target) return j;
+    }
+    return n - 1;
+}
+
+__global__ __launch_bounds__(256) void sample_ras_k(const float* __restrict__ logits, int n_all, int n_real, int* __restrict__ st, int mb,
+                                                    int* __restrict__ out_ids, int out_ld, const float* __restrict__ semb,
+                                                    float* __restrict__ h, int H, float* __restrict__ logp_keep, int keep_step,
+                                                    const float* __restrict__ uni, long n_uni, int* __restrict__ recent,
+                                                    int top_k, float top_p, int win, float rep_thr) {
+    extern __shared__ float pl[];                            // softmax(logp) in index order
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    __shared__ double cs[256];
+    __shared__ float cand_p[32];
+    __shared__ int cand_i[32];
+    __shared__ int sh_n, sh_id, sh_flag, sh_cnt;
+    __shared__ float sh_u;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (st[3 * mb + b]) return;
+    const float* x = logits + (long)b * n_all;
+    constexpr int PER = 32;
+    float xv[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = tid + u * 256;
+        xv[u] = i < n_all ? x[i] : -3.0e38f;
+    }
+    auto block_max = [&](float v) {
+        sv[tid] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) sv[tid] = fmaxf(sv[tid], sv[tid + o]); __syncthreads(); }
+        float r = sv[0];
+        __syncthreads();
+        return r;
+    };
+    auto block_sum = [&](float v) {
+        sv[tid] = v;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (tid < o) sv[tid] += sv[tid + o]; __syncthreads(); }
+        float r = sv[0];
+        __syncthreads();
+        return r;
+    };
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) mx = fmaxf(mx, xv[u]);
+    mx = block_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) if (tid + u * 256 < n_all) s += expf(xv[u] - mx);
+    const float lse = logf(block_sum(s));
+    // logp, then softmax(logp) as the reference computes it from the stored log-probabilities
+    float lpm = -3.0e38f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = tid + u * 256;
+        if (i < n_all) {
+            xv[u] = (xv[u] - mx) - lse;
+            if (logp_keep && keep_step >= 0) logp_keep[((long)keep_step * mb + b) * n_all + i] = xv[u];
+            lpm = fmaxf(lpm, xv[u]);
+        }
+    }
+    lpm = block_max(lpm);
+    float s2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) if (tid + u * 256 < n_all) { xv[u] = expf(xv[u] - lpm); s2 += xv[u]; }
+    s2 = block_sum(s2);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = tid + u * 256;
+        if (i < n_all) { xv[u] = xv[u] / s2; pl[i] = xv[u]; } else xv[u] = -1.f;
+    }
+    // nucleus: the stable descending sort's head, taken while cum < top_p and fewer than top_k (common.py:146-156)
+    if (tid == 0) { sh_n = 0; sh_flag = 0; }
+    __syncthreads();
+    float cum = 0.f;
+    for (int r = 0; r < top_k && r < 32; ++r) {
+        float best = -2.f;
+        int bi = 0x7FFFFFFF;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int i = tid + u * 256;
+            if (xv[u] > best || (xv[u] == best && i < bi)) { best = xv[u]; bi = i; }
+        }
+        sv[tid] = best; si[tid] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                float ov = sv[tid + o]; int oi = si[tid + o];
+                if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) { sv[tid] = ov; si[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        const float bp = sv[0];
+        const int bidx = si[0];
+        __syncthreads();
+        if (!(cum < top_p)) break;                           // every thread tracks cum: a uniform decision
+        if (tid == 0) { cand_p[r] = bp; cand_i[r] = bidx; sh_n = r + 1; }
+        cum += bp;
+        if ((bidx & 255) == tid) xv[bidx >> 8] = -1.f;       // taken
+    }
+    __syncthreads();
+    const int raw_n = st[1 * mb + b];
+    const bool ignore_eos = raw_n < st[5 * mb + b];
+    const int n_rec = min(raw_n, win);
+    int cnt = st[7 * mb + b];
+    bool have_cs = false;
+    const int chunk = (n_all + 255) / 256;
+    int id = -1;
+    for (int trial = 0; trial <= 100; ++trial) {             // sampling_ids: max_trials = 100, then RuntimeError
+        if (tid == 0) {
+            const float u1 = uni[(long)b * n_uni + min((long)cnt, n_uni - 1)];
+            int pick = cand_i[inv_cdf_small(cand_p, sh_n, u1)];
+            int rep = 0;
+            for (int k = 0; k < n_rec; ++k) rep += recent[k * mb + b] == pick;
+            sh_id = pick;
+            sh_flag = (float)rep >= rep_thr;
+            sh_cnt = cnt + 1;
+        }
+        __syncthreads();
+        cnt = sh_cnt;
+        if (sh_flag) {                                       // random_sampling over the whole softmax (common.py:160-162)
+            if (!have_cs) {
+                double a = 0.0;
+                for (int k = 0; k < chunk; ++k) { const int i = tid * chunk + k; if (i < n_all) a += (double)pl[i]; }
+                cs[tid] = a;
+                have_cs = true;
+                __syncthreads();
+            }
+            if (tid == 0) {
+                const float u2 = uni[(long)b * n_uni + min((long)cnt, n_uni - 1)];
+                double tot = 0.0;
+                for (int t = 0; t < 256; ++t) tot += cs[t];
+                const double target = (double)u2 * tot;
+                double c = 0.0, base = 0.0;
+                int tc = 255;
+                for (int t = 0; t < 256; ++t) { base = c; c += cs[t]; if (c > target) { tc = t; break; } }
+                int pick = min(tc * chunk + chunk - 1, n_all - 1);
+                double w = base;
+                for (int k = 0; k < chunk; ++k) {
+                    const int i = tc * chunk + k;
+                    if (i >= n_all) break;
+                    w += (double)pl[i];
+                    if (w > target) { pick = i; break; }
+                }
+                sh_id = pick;
+                sh_cnt = cnt + 1;
+            }
+            __syncthreads();
+            cnt = sh_cnt;
+        }
+        const int cand = sh_id;
+        __syncthreads();
+        if (!ignore_eos || cand < n_real) { id = cand; break; }
+    }
+    if (tid == 0) st[7 * mb + b] = cnt;
+    if (id < 0) {                            // 'sampling reaches max_trials ... and still get eos': reported by fy_llm_generate
+        if (tid == 0) st[3 * mb + b] = 2;
+        return;
+    }
+    if (id >= n_real) {                      // stop_token_ids, llm.py:520
+        if (tid == 0) st[3 * mb + b] = 1;
+        return;
+    }
+    for (int c = tid; c < H; c += 256) h[(long)b * H + c] = semb[(long)id * H + c];      // llm.py:525
+    if (tid == 0) {
+        recent[(raw_n % win) * mb + b] = id;                                   // decoded_tokens[-win_size:], order does not matter
+        int run = st[4 * mb + b];
+        bool silent = false;
+        for (int k = 0; k < 11; ++k) silent |= (c_silent[k] == id);
+        bool keep = true;
+        if (silent) { run += 1; if (run > 5) keep = false; } else run = 0;      // cli/model.py:121-127
+        st[4 * mb + b] = run;
+        if (keep) { int n = st[2 * mb + b]; if (n < out_ld) out_ids[(long)b * out_ld + n] = id; st[2 * mb + b] = n + 1; }
+        st[1 * mb + b] = raw_n + 1;
+        st[0 * mb + b] += 1;
+        if (raw_n + 1 >= st[6 * mb + b]) st[3 * mb + b] = 1;
+    }
+}
+
 // ---- create -------------------------------------------------------------------------------------------------
 static int to_bf16(fy_llm* l, const float* src, size_t n, bf16_t** dst, hipStream_t st) {
     FY_TRY(l->pool.alloc(dst, n));
@@ -301,7 +502,10 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
     return FY_OK;
 }
 
-extern "C" void fy_llm_destroy(fy_llm* l) { delete l; }
+extern "C" void fy_llm_destroy(fy_llm* l) {
+    if (l && l->recent) (void)hipFree(l->recent);
+    delete l;
+}
 
 // ---- forward over R rows (prefill rows or one decode row per sequence) ---------------------------------------------
 static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, bool decode, hipStream_t st) {
@@ -346,8 +550,13 @@ static int llm_head_and_sample(fy_llm* l, int B, const float* rows, int32_t* out
     a.norm_w = l->norm_w; a.eps = c.rms_eps;
     FY_TRY(gemv_bf16w(a, st));
     FY_CHECK(NS <= 256 * 32, FY_ERR_ARG, "sample: %d logits exceed the kernel's register tile", NS);
-    hipLaunchKernelGGL(sample_k, dim3(B), dim3(256), 0, st, l->logits, NS, c.speech_tokens, l->st, l->max_batch, out_ids, out_ld,
-                       l->speech_emb, l->h, H, l->logp_keep, keep_step < FY_LLM_KEEP_LOGP ? keep_step : -1);
+    if (l->sampler == 1)
+        hipLaunchKernelGGL(sample_ras_k, dim3(B), dim3(256), (size_t)NS * sizeof(float), st, l->logits, NS, c.speech_tokens, l->st, l->max_batch,
+                           out_ids, out_ld, l->speech_emb, l->h, H, l->logp_keep, keep_step < FY_LLM_KEEP_LOGP ? keep_step : -1,
+                           l->uniforms, l->n_uniforms, l->recent, l->top_k, l->top_p, l->win_size, l->rep_thr);
+    else
+        hipLaunchKernelGGL(sample_k, dim3(B), dim3(256), 0, st, l->logits, NS, c.speech_tokens, l->st, l->max_batch, out_ids, out_ld,
+                           l->speech_emb, l->h, H, l->logp_keep, keep_step < FY_LLM_KEEP_LOGP ? keep_step : -1);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -422,6 +631,34 @@ extern "C" int fy_llm_generate(fy_llm* l, const int32_t* text_ids, const int32_t
     HIP_TRY(hipMemcpyAsync(out_n, l->st + 2 * mb, B * sizeof(int), hipMemcpyDeviceToDevice, st));
     if (raw_n) HIP_TRY(hipMemcpyAsync(raw_n, l->st + 1 * mb, B * sizeof(int), hipMemcpyDeviceToDevice, st));
     (void)flags;
+    if (l->sampler == 1) {                   // the reference raises RuntimeError from sampling_ids (llm.py:161-162)
+        HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
+        std::vector<int> used(mb);
+        HIP_TRY(hipMemcpyAsync(used.data(), l->st + 7 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int b = 0; b < B; ++b) {
+            FY_CHECK(done[b] != 2, FY_ERR_STATE, "sampling reaches max_trials 100 and still get eos when ignore_eos is True (sequence %d)", b);
+            FY_CHECK(used[b] <= l->n_uniforms, FY_ERR_ARG, "fy_llm_generate: sequence %d needed %d uniforms, %ld were supplied", b, used[b], l->n_uniforms);
+        }
+    }
+    return FY_OK;
+}
+
+extern "C" int fy_llm_set_sampler(fy_llm* l, int32_t kind, const float* uniforms, int64_t n_uniforms, int32_t top_k, float top_p,
+                                  int32_t win_size, float tau_r) {
+    FY_CHECK(l && (kind == 0 || kind == 1), FY_ERR_ARG, "fy_llm_set_sampler: kind must be 0 (greedy) or 1 (repetition-aware sampling)");
+    if (kind == 1) {
+        FY_CHECK(uniforms && n_uniforms >= 1 && top_k >= 1 && top_k <= 32 && top_p > 0.f && win_size >= 1 && win_size <= 64 && tau_r >= 0.f,
+                 FY_ERR_ARG, "fy_llm_set_sampler: bad sampling parameters");
+        if (!l->recent || win_size != l->win_size) {
+            if (l->recent) (void)hipFree(l->recent);
+            l->recent = nullptr;
+            HIP_TRY(hipMalloc(&l->recent, (size_t)win_size * l->max_batch * sizeof(int)));
+        }
+        l->uniforms = uniforms; l->n_uniforms = n_uniforms; l->top_k = top_k; l->top_p = top_p; l->win_size = win_size;
+        l->rep_thr = (float)((double)win_size * (double)tau_r);
+    }
+    l->sampler = kind;
     return FY_OK;
 }
 

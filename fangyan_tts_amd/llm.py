@@ -97,6 +97,21 @@ class LlmEngine:
                                          out_n.data_ptr(), raw_n.data_ptr(), 0, self._stream()))
         return out, out_n, raw_n
 
+    def set_sampler(self, kind: str = "greedy", uniforms: Optional[torch.Tensor] = None, top_k: int = 25, top_p: float = 0.8,
+                    win_size: int = 10, tau_r: float = 0.1):
+        """"greedy" (SURVEY 8 a4 rule) or "ras": the reference's default repetition-aware sampling (utils/common.py:137-166,
+        parameters of cosyvoice3.yaml) with torch.multinomial's draws replaced by the inverse CDF at `uniforms`
+        (float32 CUDA (max_batch, n), one row per sequence, consumed from the start at every generate call)."""
+        if kind == "greedy":
+            check(_lib.lib().fy_llm_set_sampler(self._h, 0, None, 0, top_k, top_p, win_size, tau_r))
+            self._uniforms = None
+            return
+        assert kind == "ras" and uniforms is not None and uniforms.is_cuda and uniforms.dtype == torch.float32
+        u = uniforms.reshape(-1, uniforms.shape[-1]).contiguous()
+        assert u.shape[0] >= self.max_batch, "one row of uniforms per sequence slot"
+        self._uniforms = u                                   # borrowed by the library until the next call
+        check(_lib.lib().fy_llm_set_sampler(self._h, 1, u.data_ptr(), u.shape[1], top_k, top_p, win_size, tau_r))
+
     def logp(self, step: int, B: int) -> torch.Tensor:
         buf = torch.empty(B, self.cfg.n_speech, device=self.device)
         check(_lib.lib().fy_llm_logp(self._h, step, buf.data_ptr(), self._stream()))

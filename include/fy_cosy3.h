@@ -154,6 +154,14 @@ void fy_llm_destroy(fy_llm* l);
 int fy_llm_generate(fy_llm* l, const int32_t* text_ids, const int32_t* n_text_all, const int32_t* prompt_speech,
                     const int32_t* n_prompt_speech, const int32_t* min_len, const int32_t* max_len, int32_t B,
                     int32_t* out_ids, int32_t out_ld, int32_t* out_n, int32_t* raw_n, uint32_t flags, void* stream);
+/* Sampler used by the following fy_llm_generate calls.  kind 0: the greedy rule above.  kind 1: the reference's default,
+ * repetition-aware sampling (utils/common.py:137-166 `ras_sampling` with top_p, top_k, win_size, tau_r = 0.8, 25, 10, 0.1 in
+ * cosyvoice3.yaml) inside the ignore_eos retry loop of `sampling_ids` (llm/llm.py:149-164; > 100 retries -> FY_ERR_STATE with
+ * the reference's message).  torch.multinomial's draws are replaced by the inverse CDF at caller-supplied uniforms:
+ * `uniforms` is device fp32 (max_batch, n_uniforms), borrowed until the next call; sequence b consumes its row from the
+ * start of every fy_llm_generate call, one value per multinomial the reference would draw.                               */
+int fy_llm_set_sampler(fy_llm* l, int32_t kind, const float* uniforms, int64_t n_uniforms, int32_t top_k, float top_p,
+                       int32_t win_size, float tau_r);
 /* log_softmax of step `step` (0 = first generated token) of the last fy_llm_generate call, (B, speech_tokens+200).
  * Only the first FY_LLM_KEEP_LOGP steps are kept.                                                            */
 #define FY_LLM_KEEP_LOGP 4

@@ -114,6 +114,99 @@ def greedy_id(logp: torch.Tensor, ignore_eos: bool, cfg: LlmCfg) -> int:
     return int(torch.argmax(logp))
 
 
+def inv_cdf(p, u: float) -> int:
+    """The draw that stands in for `torch.multinomial(p, 1)`: torch draws from its global generator, which
+    no other implementation can follow, so the draw is DEFINED (here, in the fixture mint, which patches
+    Tensor.multinomial with this function, and in csrc/llm.hip:sample_ras_k) as the inverse CDF at a supplied
+    uniform u in [0, 1).  Weights are summed in float64, in index order, in chunks of ceil(n/256): chunk sums,
+    a running sum over the chunks, then a running sum inside the chosen chunk started from the total of the
+    chunks before it; the sample is the first index whose running sum exceeds u * total."""
+    import numpy as np
+    w = np.asarray(p, dtype=np.float32).astype(np.float64).reshape(-1)
+    n = w.size
+    chunk = (n + 255) // 256
+    cs = np.zeros(256, dtype=np.float64)
+    for t in range(256):
+        seg = w[t * chunk: min((t + 1) * chunk, n)]
+        a = np.float64(0.0)
+        for v in seg:                                     # sequential, as one GPU thread does it
+            a = a + v
+        cs[t] = a
+    tot = np.float64(0.0)
+    for t in range(256):
+        tot = tot + cs[t]
+    target = np.float64(np.float32(u)) * tot
+    c, base, tc = np.float64(0.0), np.float64(0.0), 255
+    for t in range(256):
+        base = c
+        c = c + cs[t]
+        if c > target:
+            tc = t
+            break
+    pick = min(tc * chunk + chunk - 1, n - 1)
+    wsum = base
+    for k in range(chunk):
+        i = tc * chunk + k
+        if i >= n:
+            break
+        wsum = wsum + w[i]
+        if wsum > target:
+            pick = i
+            break
+    return int(pick)
+
+
+class UniformStream:
+    """The supplied uniforms, consumed one per multinomial draw."""
+
+    def __init__(self, values):
+        self.values, self.pos = values, 0
+
+    def next(self) -> float:
+        v = float(self.values[self.pos])
+        self.pos += 1
+        return v
+
+
+def nucleus_sampling(logp: torch.Tensor, us: UniformStream, top_p: float = 0.8, top_k: int = 25) -> int:
+    """utils/common.py:146-159."""
+    prob, indices = [], []
+    cum_prob = 0.0
+    sorted_value, sorted_idx = logp.softmax(dim=0).sort(descending=True, stable=True)
+    for i in range(len(sorted_idx)):
+        if cum_prob < top_p and len(prob) < top_k:
+            cum_prob += sorted_value[i]
+            prob.append(sorted_value[i])
+            indices.append(sorted_idx[i])
+        else:
+            break
+    prob = torch.tensor(prob).to(logp)
+    return int(indices[inv_cdf(prob.numpy(), us.next())])
+
+
+def ras_id(logp: torch.Tensor, decoded: List[int], us: UniformStream, top_p=0.8, top_k=25, win_size=10, tau_r=0.1) -> int:
+    """ras_sampling, utils/common.py:137-143 (repetition aware sampling): a nucleus draw; when it already occurs in the
+    last win_size tokens at least win_size*tau_r times, a draw from the whole softmax replaces it (:160-162)."""
+    top = nucleus_sampling(logp, us, top_p, top_k)
+    rep_num = int((torch.tensor(decoded[-win_size:]) == top).sum()) if decoded else 0
+    if rep_num >= win_size * tau_r:
+        top = inv_cdf(logp.softmax(dim=0).numpy(), us.next())
+    return int(top)
+
+
+def sampling_ids(logp: torch.Tensor, decoded: List[int], us: UniformStream, ignore_eos: bool, cfg: LlmCfg) -> int:
+    """TransformerLM.sampling_ids, llm/llm.py:149-164."""
+    num_trials, max_trials = 0, 100
+    while True:
+        top = ras_id(logp, decoded, us)
+        if (not ignore_eos) or top < cfg.speech_tokens:
+            break
+        num_trials += 1
+        if num_trials > max_trials:
+            raise RuntimeError("sampling reaches max_trials {} and still get eos when ignore_eos is True, check your input!".format(max_trials))
+    return top
+
+
 def lm_input(text, prompt_text, prompt_speech_token, P: Params, cfg: LlmCfg):
     """CosyVoice3LM.inference, llm/llm.py:728-744: [sos, embed(prompt_text+text),
     task_id, speech_embedding(prompt_speech_token)] and (min_len, max_len)."""
@@ -129,23 +222,27 @@ def lm_input(text, prompt_text, prompt_speech_token, P: Params, cfg: LlmCfg):
 
 def inference(text, prompt_text, prompt_speech_token, P: Params, cfg: LlmCfg,
               min_len: Optional[int] = None, max_len: Optional[int] = None,
-              logp_out: Optional[list] = None) -> Iterator[int]:
+              logp_out: Optional[list] = None, uniforms=None) -> Iterator[int]:
     """CosyVoice3LM.inference + Qwen2LM.inference_wrapper (HF branch),
-    llm/llm.py:713-748 and :511-525, with the greedy rule above."""
+    llm/llm.py:713-748 and :511-525, with the greedy rule above, or - when `uniforms` is given - the reference's
+    default repetition-aware sampling with its multinomial draws taken from that stream (inv_cdf)."""
     with torch.no_grad():
         x, mn, mx = lm_input(text, prompt_text, prompt_speech_token, P, cfg)
         min_len = mn if min_len is None else min_len
         max_len = mx if max_len is None else max_len
         cache = KVCache(cfg.layers)
+        us = UniformStream(uniforms) if uniforms is not None else None
+        out_tokens: List[int] = []
         for i in range(max_len):
             y = forward_one_step(x, cache, P, cfg)
             logp = F.linear(y[:, -1], P["llm_decoder.weight"]).log_softmax(dim=-1).squeeze(0)
             if logp_out is not None:
                 logp_out.append(logp.clone())
-            tid = greedy_id(logp, i < min_len, cfg)
+            tid = greedy_id(logp, i < min_len, cfg) if us is None else sampling_ids(logp, out_tokens, us, i < min_len, cfg)
             if tid >= cfg.speech_tokens:                   # stop_token_ids, llm.py:520,667
                 break
             yield tid
+            out_tokens.append(tid)
             x = P["speech_embedding.weight"][tid].reshape(1, 1, -1)
 
 

@@ -331,6 +331,55 @@ def mint_llm(tag, cfg: LlmCfg, cases, out, max_steps):
     np.savez_compressed(os.path.join(out, f"llm_{tag}.npz"), **fx)
 
 
+def mint_llm_ras(tag, cfg: LlmCfg, cases, out, max_steps):
+    """The reference's DEFAULT sampler: ras_sampling (utils/common.py:137-166) inside sampling_ids (llm/llm.py:149-164), with the
+    one thing no other implementation can follow - torch.multinomial's draws from the global generator - replaced by the
+    inverse CDF at supplied uniforms (oracle.llm.inv_cdf), by patching Tensor.multinomial for the duration of the run."""
+    from functools import partial
+    from cosyvoice.utils.common import ras_sampling
+    from oracle import llm as ollm
+    m = build_llm(cfg)
+    m.sampling = partial(ras_sampling, top_p=0.8, top_k=25, win_size=10, tau_r=0.1)          # cosyvoice3.yaml:32-36
+    fx = {}
+    orig = torch.Tensor.multinomial
+    for (n_text, n_ptext, p_tok) in cases:
+        ctag = f"{n_text}_{n_ptext}_{p_tok}"
+        text, ptext, ptok = llm_case(cfg, n_text, n_ptext, p_tok, ctag)
+        u = synth.uniform(f"in.llm.ras_u.{ctag}", (4096,), 0.0, 1.0)
+        stream = ollm.UniformStream(u)
+        draws = {"nucleus": 0, "full": 0}
+
+        def fake_multinomial(self, num_samples, replacement=False, generator=None):
+            assert num_samples == 1 and self.dim() == 1
+            draws["full" if self.numel() > 32 else "nucleus"] += 1
+            return torch.tensor([ollm.inv_cdf(self.detach().float().numpy(), stream.next())], dtype=torch.long)
+        torch.Tensor.multinomial = fake_multinomial
+        toks = []
+        t0 = time.time()
+        raised = ""
+        try:
+            with torch.inference_mode():
+                for tid in m.inference(text=text, text_len=torch.tensor([n_text], dtype=torch.int32),
+                                       prompt_text=ptext, prompt_text_len=torch.tensor([n_ptext], dtype=torch.int32),
+                                       prompt_speech_token=ptok, prompt_speech_token_len=torch.tensor([p_tok], dtype=torch.int32),
+                                       embedding=torch.zeros(0, 192)):
+                    toks.append(int(tid))
+                    if len(toks) >= max_steps:
+                        break
+        except RuntimeError as e:                 # sampling_ids gives up after 100 eos draws below min_len (llm.py:161-162)
+            raised = str(e)
+        finally:
+            torch.Tensor.multinomial = orig
+        fx[f"c{ctag}.raised"] = np.asarray(raised)
+        print(f"[llm-ras {tag}] case {ctag}: raised {raised!r}; {len(toks)} tokens (min_len {2 * n_text}) in {time.time() - t0:.1f}s; draws {draws}, "
+              f"{stream.pos} uniforms; first ids {toks[:8]}")
+        fx[f"c{ctag}.tokens"] = np.asarray(toks, dtype=np.int32)
+        fx[f"c{ctag}.capped"] = np.asarray(len(toks) >= max_steps)
+        fx[f"c{ctag}.uniforms_used"] = np.asarray(stream.pos)
+        fx[f"c{ctag}.full_draws"] = np.asarray(draws["full"])
+    np.savez_compressed(os.path.join(out, f"llm_ras_{tag}.npz"), **fx)
+
+
 def mint_e2e(tag, cfg: ModelCfg, cases, out):
     """CosyVoice3Model.tts(stream=False) of the reference: dict -> ids -> mel -> wav."""
     from cosyvoice.cli.model import CosyVoice3Model
@@ -441,7 +490,7 @@ def mint_stream(tag, cfg: ModelCfg, hift_frames, flow_case, e2e_cases, out):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="hift,flow,llm,e2e,stream")
+    ap.add_argument("--only", default="hift,flow,llm,e2e,stream,ras")
     ap.add_argument("--full", action="store_true", help="also mint the full-size (CosyVoice3-0.5B shape) fixtures")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
@@ -465,6 +514,10 @@ def main():
         mint_e2e("tiny", tiny, [(8, 6, 0, 12), (6, 5, 20, 20)], a.out)
         if a.full:
             mint_e2e("full", ModelCfg(), [(8, 8, 0, 25)], a.out)
+    if "ras" in only:
+        mint_llm_ras("tiny", tiny.llm, [(12, 8, 0), (10, 6, 30), (16, 4, 10), (30, 5, 0)], a.out, max_steps=400)
+        if a.full:
+            mint_llm_ras("full", LlmCfg(), [(12, 8, 0)], a.out, max_steps=60)
     if "stream" in only:
         mint_stream("tiny", tiny, [30], (31, 10), [(40, 6, 0, 12)], a.out)
         if a.full:

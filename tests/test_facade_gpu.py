@@ -77,7 +77,8 @@ def model_dir(tmp_path_factory):
 def test_automodel_drop_in_calls(model_dir):
     from cosyvoice.cli.cosyvoice import AutoModel                            # the reference's import path
     path, cfg = model_dir
-    model = AutoModel(model_dir=path, frontend=FakeFrontEnd(cfg), max_tokens=160, max_prompt_tokens=32)
+    model = AutoModel(model_dir=path, frontend=FakeFrontEnd(cfg), max_tokens=160, max_prompt_tokens=32, sampler="greedy")
+    assert model.model.sampler == "greedy"        # the facade's default is the reference's ("ras"); greedy makes the calls below comparable
     assert model.sample_rate == 24000 and model.cfg == cfg
     outs = list(model.inference_instruct2("你好世界", "用四川话说<|endofprompt|>", "prompt.wav", stream=False))
     assert len(outs) == 1

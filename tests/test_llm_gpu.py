@@ -82,3 +82,62 @@ def test_forced_length_and_min_len(tiny):
     assert raw_n.cpu().tolist() == [40, 33]
     o = out.cpu()
     assert int(o[0, :40].max()) < cfg.speech_tokens and int(o[1, :33].max()) < cfg.speech_tokens
+
+
+def _ras_rows(cases, n_rows):
+    u = np.zeros((n_rows, 4096), dtype=np.float32)
+    for b, c in enumerate(cases):
+        u[b] = synth.uniform("in.llm.ras_u.%d_%d_%d" % c, (4096,), 0.0, 1.0)
+    return torch.from_numpy(u).to(DEV)
+
+
+def test_ras_tokens_against_reference(tiny):
+    """The reference's default sampler (ras_sampling inside sampling_ids) on the device, multinomial draws from the supplied
+    uniforms: ids identical to the reference's own run (tests/golden/llm_ras_tiny.npz), batched; the reference's give-up
+    RuntimeError surfaces with its message; greedy decoding is back afterwards."""
+    from oracle.llm import silent_filter
+    f = golden("llm_ras_tiny.npz")
+    assert f is not None
+    cfg = tiny.cfg
+    cases = [(12, 8, 0), (16, 4, 10), (30, 5, 0)]
+    texts, ptexts, ptoks = zip(*[llm_case(cfg, *c, "%d_%d_%d" % c) for c in cases])
+    tiny.set_sampler("ras", _ras_rows(cases, tiny.max_batch))
+    try:
+        out, out_n, raw_n = tiny.generate(list(texts), list(ptexts), list(ptoks), max_len=[min(20 * len(t), 400) for t in texts])
+        out, out_n = out.cpu(), out_n.cpu().tolist()
+        for b, c in enumerate(cases):
+            ref = silent_filter(f["c%d_%d_%d.tokens" % c].tolist())
+            got = out[b, : out_n[b]].tolist()
+            first_bad = next((i for i, (g, r) in enumerate(zip(got, ref)) if g != r), None)
+            note("parity_llm.json", f"ras.tiny.{c}.n", [len(got), len(ref), first_bad])
+            assert got == ref, (c, first_bad, got[:10], ref[:10])
+        bad = (10, 6, 30)
+        assert "max_trials" in str(f["c%d_%d_%d.raised" % bad])
+        t, pt, pk = llm_case(cfg, *bad, "%d_%d_%d" % bad)
+        tiny.set_sampler("ras", _ras_rows([bad], tiny.max_batch))
+        with pytest.raises(RuntimeError, match="sampling reaches max_trials 100"):
+            tiny.generate([t], [pt], [pk])
+    finally:
+        tiny.set_sampler("greedy")
+    f0 = golden("llm_tiny.npz")
+    run_cases(tiny, f0, [(12, 8, 0)], None, "tiny_after_ras")
+
+
+def test_ras_full_size(full):
+    f = golden("llm_ras_full.npz")
+    if f is None:
+        pytest.skip("llm_ras_full.npz not minted")
+    from oracle.llm import silent_filter
+    c = (12, 8, 0)
+    t, pt, pk = llm_case(full.cfg, *c, "%d_%d_%d" % c)
+    full.set_sampler("ras", _ras_rows([c], full.max_batch))
+    try:
+        if str(f["c%d_%d_%d.raised" % c]):
+            with pytest.raises(RuntimeError, match="sampling reaches max_trials 100"):
+                full.generate([t], [pt], [pk], max_len=[60])
+        else:
+            out, out_n, _ = full.generate([t], [pt], [pk], max_len=[60])
+            ref = silent_filter(f["c%d_%d_%d.tokens" % c].tolist())[:60]
+            assert out[0, : int(out_n[0])].cpu().tolist() == ref
+    finally:
+        full.set_sampler("greedy")

@@ -269,3 +269,38 @@ def test_stream_against_reference():
     for i, c in enumerate(out["chunks"]):
         check(c, f, f"e2e.c{ctag}.chunk{i}", 1e-3, 1e-4)
     check(out["tts_speech"], f, f"e2e.c{ctag}.wav", 1e-3, 1e-4)
+
+
+# ------------------------------------------------------------------ the reference's default sampler
+
+def test_inv_cdf_is_a_sampler():
+    """The stand-in for torch.multinomial: monotone in u, exact on dyadic weights, never an index of zero weight."""
+    p = np.array([0.25, 0.0, 0.5, 0.25], dtype=np.float32)
+    assert [ollm.inv_cdf(p, u) for u in (0.0, 0.2499, 0.25, 0.7499, 0.75, 0.9999)] == [0, 0, 2, 2, 3, 3]
+    rng = np.random.default_rng(0)
+    w = rng.random(6761).astype(np.float32)
+    us = np.sort(rng.random(200).astype(np.float32))
+    picks = [ollm.inv_cdf(w, u) for u in us]
+    assert picks == sorted(picks)
+    cdf = np.cumsum(w.astype(np.float64)) / w.astype(np.float64).sum()
+    assert all(abs(cdf[i] - u) < 1e-3 for i, u in zip(picks, us))
+
+
+def test_llm_ras_against_reference():
+    """ras_sampling inside sampling_ids, draws from the supplied uniforms: token ids identical to the reference's, the
+    give-up RuntimeError included."""
+    f = fx("llm_ras_tiny.npz")
+    cfg = ModelCfg.tiny().llm
+    P = ollm.prepare(synth.state_dict(cfg.manifest()))
+    for (n_text, n_ptext, p_tok) in ((12, 8, 0), (10, 6, 30), (16, 4, 10), (30, 5, 0)):
+        ctag = f"{n_text}_{n_ptext}_{p_tok}"
+        text, ptext, ptok = llm_case(cfg, n_text, n_ptext, p_tok, ctag)
+        u = synth.uniform(f"in.llm.ras_u.{ctag}", (4096,), 0.0, 1.0)
+        toks, raised = [], ""
+        try:
+            for t in ollm.inference(text, ptext, ptok, P, cfg, uniforms=u):
+                toks.append(t)
+        except RuntimeError as e:
+            raised = str(e)
+        assert raised == str(f[f"c{ctag}.raised"])
+        assert toks == f[f"c{ctag}.tokens"].tolist()
