@@ -1,9 +1,9 @@
 // 1-D causal convolution kernels over channels-last fp32 activations.
-//   conv1d_f32_direct : exact fp32 VALU kernel, any shape (f0 predictor, source
-//                       down-samplers, conv_post, PreLookahead) and the on-GPU
-//                       cross-check of the MFMA kernel.
-//   conv1d_f32_mfma   : the same arithmetic as conv1d_f32_direct on the fp32 matrix
-//                       instruction (f0 predictor).
+//   conv1d_f32_direct : exact fp32 VALU kernel, any shape: the FY_DIRECT cross-check
+//                       of every conv and the layers of reduced-size models that
+//                       the MFMA tilings do not fit.
+//   conv1d_f32_mfma   : the same arithmetic on the fp32 matrix instruction (f0
+//                       predictor, PreLookahead - the layers that must stay fp32).
 //   conv1d_bf16_mfma  : implicit GEMM on v_mfma_f32_32x32x16_bf16; the input tile
 //                       (+ causal halo) is activated once and staged in LDS as
 //                       bf16, the taps walk LDS rows, weights stream from L2 in

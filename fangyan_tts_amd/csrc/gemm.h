@@ -1,8 +1,10 @@
 // Dense products for the DiT estimator and the Qwen2 speech-token LM.
-//   gemm_bf16   : C[M,N] = A[M,K] * W[N,K]^T on v_mfma_f32_32x32x16_bf16, 128x128x32 block tile,
-//                 A and W both K-contiguous (torch Linear layout), fused epilogues.
-//   gemv_bf16w  : y[r,n] = sum_k W[n,k] x[r,k] for r < 8 rows of fp32 activations against bf16
-//                 weights in fp32 VALU arithmetic - the HBM-bound LLM decode product.
+//   gemm_bf16   : C[M,N] = A[M,K] * W[N,K]^T on v_mfma_f32_32x32x16_bf16, A and W both K-contiguous
+//                 (torch Linear layout), fused epilogues; 256x256x32 tiles fed by an LDS-DMA ring for the
+//                 wide products, 128x128x64 register-staged tiles otherwise (gemm.hip says when and why).
+//   gemv_bf16w  : y[r,n] = sum_k W[n,k] x[r,k] for r <= 8 rows of fp32 activations against bf16 weights,
+//                 fp32-faithful on the matrix cores (exact 3-way bf16 split of the activations) - the
+//                 LLM decode product.
 #pragma once
 #include "common.h"
 
