@@ -118,6 +118,38 @@ __global__ __launch_bounds__(256) void ln_mod_k(const float* __restrict__ h, con
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const float* p = h + (long)row * D;
+    if ((D & 255) == 0 && D <= 1024) {                       // 16-byte loads, 8-byte stores: four columns per lane and pass
+        const int per4 = D / 256;                            // <= 4
+        float4 v[4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = i < per4 ? *reinterpret_cast<const float4*>(p + (lane + 64 * i) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        const float mean = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < per4) {
+                const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+                q += (a * a + b * b) + (c * c + d * d);
+            }
+        const float rstd = rsqrtf(wave_sum(q) / D + 1e-6f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < per4) {
+                const int c = (lane + 64 * i) * 4;
+                const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16((v[i].x - mean) * rstd * (1.f + sc.x) + sh.x) |
+                       ((uint32_t)f32_to_bf16((v[i].y - mean) * rstd * (1.f + sc.y) + sh.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16((v[i].z - mean) * rstd * (1.f + sc.z) + sh.z) |
+                       ((uint32_t)f32_to_bf16((v[i].w - mean) * rstd * (1.f + sc.w) + sh.w) << 16);
+                *reinterpret_cast<uint2*>(out + (long)row * D + c) = pk;
+            }
+        return;
+    }
     float v[16];
     const int per = D / 64;                   // <= 16
     float s = 0.f;
