@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
     ap.add_argument("--llm-streams", type=int, default=2, help="LM handles decoding different steps' batches concurrently")
+    ap.add_argument("--lm-isolate", action="store_true", help="LM streams run ONLY on the CUs the flow stream is kept off")
+    ap.add_argument("--lm-group", type=int, default=1, help="consecutive steps whose LM decode runs as one call")
     ap.add_argument("--flow-cu-exclude", type=int, default=None, help="CUs kept clear of the flow / vocoder stream")
     a = ap.parse_args()
 
@@ -119,7 +121,7 @@ def main():
     ri = torch.from_numpy(synth.hift_rand_ini()).to(dev)
     sn = torch.from_numpy(synth.hift_sine_noise(2 * N_TOK * 480)).to(dev)
     model = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=BATCH, max_text=64, max_prompt_tokens=P_TOK,
-                            max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn, n_llm=1 if a.no_pipeline else a.llm_streams)
+                            max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn, n_llm=1 if a.no_pipeline else a.llm_streams, lm_group=1 if a.no_pipeline else a.lm_group)
     log("engines ready")
     inputs = make_inputs(cfg, rank)
     forced = [N_TOK] * BATCH
@@ -138,7 +140,7 @@ def main():
             return [step() for _ in range(k)][-1]
         samples = None
         for wav, samples, _ in model.tts_pipeline([inputs] * k, min_len=[forced] * k, max_len=[forced] * k, keep_on_device=True,
-                                                  flow_cu_exclude=a.flow_cu_exclude):
+                                                  flow_cu_exclude=a.flow_cu_exclude, lm_isolate=a.lm_isolate):
             if world > 1:
                 gather_audio(wav.cpu() if rehearsal else wav, samples)
         return samples
@@ -201,7 +203,7 @@ def main():
         "config": {"workload": "CosyVoice3-0.5B instruct (inference_instruct2), batch 8 mixed-length utterances per GPU, "
                                "5 s prompt, 75 forced speech tokens (3 s) each, LM greedy -> 10-step CFG flow (DiT-22) -> HiFT",
                    "batch_per_gpu": BATCH, "tokens_per_utt": N_TOK, "prompt_tokens": P_TOK, "parallelism": f"dp{world}",
-                   "steps_pipelined": not a.no_pipeline, "llm_streams": 1 if a.no_pipeline else a.llm_streams, "flow_cu_exclude": a.flow_cu_exclude, "batch_latency_ms_unpipelined": round(latency_ms, 1),
+                   "steps_pipelined": not a.no_pipeline, "llm_streams": 1 if a.no_pipeline else a.llm_streams, "lm_group": 1 if a.no_pipeline else a.lm_group, "flow_cu_exclude": a.flow_cu_exclude, "batch_latency_ms_unpipelined": round(latency_ms, 1),
                    "weights": "random-init, CosyVoice3-0.5B shapes (859 M params)"},
         "roofline": roofline,
     }

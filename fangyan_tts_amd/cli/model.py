@@ -24,7 +24,7 @@ class CosyVoice3Model:
                  max_batch: int = 8, max_text: int = 128, max_prompt_tokens: int = 800, max_tokens: int = 800,
                  rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
                  sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False, n_llm: int = 1,
-                 sampler: str = "greedy", sampler_seed: int = 1986):
+                 sampler: str = "greedy", sampler_seed: int = 1986, lm_group: int = 1):
         if not torch.cuda.is_available():
             raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -33,7 +33,10 @@ class CosyVoice3Model:
         max_frames = 2 * (max_tokens + max_prompt_tokens)
         # n_llm > 1: extra LM handles (own KV cache and workspace) so tts_pipeline can decode several batches at once;
         # one decode stream uses a few dozen workgroups per launch and is bound by launch latency, not by the chip
-        self.llms = [LlmEngine(llm_weights, cfg.llm, max_batch=max_batch, max_ctx=2 + max_text + max_prompt_tokens + max_tokens,
+        # lm_group > 1: tts_pipeline decodes that many consecutive batches in ONE LM call (the weights stream once per
+        # decode step for all of them and the launch count per batch drops), then runs flow + vocoder batch by batch
+        self.lm_group = max(1, lm_group)
+        self.llms = [LlmEngine(llm_weights, cfg.llm, max_batch=max_batch * self.lm_group, max_ctx=2 + max_text + max_prompt_tokens + max_tokens,
                                device=self.device, keep_weights=keep_llm_weights and i == 0) for i in range(max(1, n_llm))]
         self.llm = self.llms[0]
         self.flow = FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device)
@@ -51,7 +54,7 @@ class CosyVoice3Model:
         # multinomial draws come from fresh uniforms (one row per sequence slot) drawn before every LM call
         self.sampler = sampler
         self._sampler_gen = torch.Generator(device=self.device).manual_seed(sampler_seed)
-        self._uniforms = [torch.zeros(max_batch, 4 * max_tokens + 256, device=self.device) for _ in self.llms] if sampler == "ras" else None
+        self._uniforms = [torch.zeros(max_batch * self.lm_group, 4 * max_tokens + 256, device=self.device) for _ in self.llms] if sampler == "ras" else None
         assert sampler in ("greedy", "ras")
 
     def _arm_sampler(self, i: int = 0):
@@ -84,7 +87,7 @@ class CosyVoice3Model:
     # ------------------------------------------------------------------ pipelined batches
     @torch.inference_mode()
     def tts_pipeline(self, batches: Sequence[Sequence[Dict[str, torch.Tensor]]], min_len=None, max_len=None,
-                     keep_on_device: bool = False, flow_cu_exclude: Optional[int] = None):
+                     keep_on_device: bool = False, flow_cu_exclude: Optional[int] = None, lm_isolate: bool = False):
         """Consecutive batches, software-pipelined over HIP streams: the speech-token LM of the next batches
         (latency-bound, a few workgroups per launch; one stream per LM handle, `n_llm` of them) runs beside the
         flow decoder + vocoder of batch i (throughput-bound).  Yields (wav, n_samples, tokens) per batch, in
@@ -93,32 +96,52 @@ class CosyVoice3Model:
         flow_cu_exclude: CUs the flow / vocoder stream may NOT use (hipExtStreamCreateWithCUMask).  The LM's short
         kernels otherwise queue behind GEMM workgroups that hold every CU's LDS; measured on MI355X at batch 8 the
         stage time with ONE LM handle is 137 ms with no mask and 126 ms with 80 CUs kept clear; with TWO LM handles
-        it is 106 ms with no mask and the mask only hurts (175-200 ms).  None = 80 for one handle, 0 (no mask) otherwise."""
+        it is 106 ms with no mask and the mask only hurts (175-200 ms).  None = 80 for one handle, 0 (no mask) otherwise.
+        lm_isolate additionally confines the LM streams to the excluded CUs (complementary masks); measured slower at every
+        split (32-96 CUs: 104-170 ms per step against 91 unmasked): the decode kernels want the whole chip for their short bursts.
+        Set FY_PIPE_TRACE=1 for per-stage wall times on stderr."""
+        import os
         import queue
+        import sys
         import threading as th
+        import time
+        trace = bool(os.environ.get("FY_PIPE_TRACE"))        # per-stage wall times on stderr
         dev = self.device
         n_prod = len(self.llms)
         if flow_cu_exclude is None:
             flow_cu_exclude = 80 if n_prod == 1 else 0
         s_fv = self._masked_stream(flow_cu_exclude) if flow_cu_exclude > 0 else torch.cuda.Stream(device=dev)
-        qs = [queue.Queue(maxsize=2) for _ in range(n_prod)]
+        qs = [queue.Queue(maxsize=2 * self.lm_group) for _ in range(n_prod)]
         z = torch.zeros(1, 0, dtype=torch.int32)
 
         def producer(pi):
             llm, q = self.llms[pi], qs[pi]
             try:
-                with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev, priority=-1)):
-                    for bi in range(pi, len(batches), n_prod):
-                        inputs = batches[bi]
-                        text = [d["text"].reshape(-1).tolist() for d in inputs]
-                        ptext = [d.get("prompt_text", z).reshape(-1).tolist() for d in inputs]
-                        pspeech = [d.get("llm_prompt_speech_token", z).reshape(-1).tolist() for d in inputs]
-                        mn = min_len[bi] if min_len is not None else None
-                        mx = max_len[bi] if max_len is not None else None
+                lm_stream = self._masked_stream(flow_cu_exclude, only=True, tag=pi) if (flow_cu_exclude > 0 and lm_isolate) else \
+                    torch.cuda.Stream(device=dev, priority=-1)
+                with torch.cuda.device(dev), torch.cuda.stream(lm_stream):
+                    G = self.lm_group
+                    for g0 in range(pi * G, len(batches), n_prod * G):
+                        group = list(range(g0, min(g0 + G, len(batches))))
+                        text, ptext, pspeech, mn, mx = [], [], [], [], []
+                        for bi in group:
+                            inputs = batches[bi]
+                            text += [d["text"].reshape(-1).tolist() for d in inputs]
+                            ptext += [d.get("prompt_text", z).reshape(-1).tolist() for d in inputs]
+                            pspeech += [d.get("llm_prompt_speech_token", z).reshape(-1).tolist() for d in inputs]
+                            mn += list(min_len[bi]) if min_len is not None else [int(len(d["text"].reshape(-1)) * 2) for d in inputs]
+                            mx += list(max_len[bi]) if max_len is not None else [int(len(d["text"].reshape(-1)) * 20) for d in inputs]
                         self._arm_sampler(pi)
+                        t0 = time.perf_counter()
                         out, out_n, _ = llm.generate(text, ptext, pspeech, min_len=mn, max_len=mx)
                         n_tok = out_n.cpu().tolist()              # synchronises the LM stream: the ids are complete
-                        q.put((inputs, out, n_tok))
+                        if trace:
+                            print(f"[pipe] LM handle {pi} batches {group}: {1e3 * (time.perf_counter() - t0):.1f} ms", file=sys.stderr)
+                        o = 0
+                        for bi in group:
+                            nb = len(batches[bi])
+                            q.put((batches[bi], out[o: o + nb], n_tok[o: o + nb]))
+                            o += nb
             except BaseException as e:                             # surfaces in the consumer
                 q.put(e)
 
@@ -128,7 +151,9 @@ class CosyVoice3Model:
                 t.start()
             with torch.cuda.stream(s_fv):
                 for bi in range(len(batches)):
-                    item = qs[bi % n_prod].get()
+                    t0 = time.perf_counter()
+                    item = qs[(bi // self.lm_group) % n_prod].get()
+                    t1 = time.perf_counter()
                     if isinstance(item, BaseException):
                         raise item
                     inputs, out, n_tok = item
@@ -136,27 +161,34 @@ class CosyVoice3Model:
                         raise RuntimeError("the language model emitted no speech token for an utterance")
                     wav, samples = self._token2wav(inputs, out, n_tok, 1.0)
                     s_fv.synchronize()
+                    if trace:
+                        print(f"[pipe] batch {bi}: waited {1e3 * (t1 - t0):.1f} ms for ids, flow+vocoder {1e3 * (time.perf_counter() - t1):.1f} ms",
+                              file=sys.stderr)
                     yield (wav if keep_on_device else wav.cpu()), samples, [out[b, : n_tok[b]] for b in range(len(inputs))]
             for t in threads:
                 t.join()
 
-    def _masked_stream(self, exclude: int):
-        """A HIP stream whose kernels may not run on the first `exclude` CUs (cached per value)."""
+    def _masked_stream(self, exclude: int, only: bool = False, tag: int = 0):
+        """A HIP stream whose kernels may not run on the first `exclude` CUs of the mask - or, with only=True, may run on
+        nothing but those (cached per (value, only, tag))."""
         cache = self.__dict__.setdefault("_masked_streams", {})
-        if exclude not in cache:
+        key = (exclude, only, tag)
+        if key not in cache:
             import ctypes
             hip = ctypes.CDLL("libamdhip64.so")
             n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
-            words = (ctypes.c_uint32 * ((n_cu + 31) // 32))(*([0xFFFFFFFF] * ((n_cu + 31) // 32)))
-            for i in range(min(exclude, n_cu - 1)):
-                words[i // 32] &= ~(1 << (i % 32))
+            words = (ctypes.c_uint32 * ((n_cu + 31) // 32))(*([0] * ((n_cu + 31) // 32)))
+            for i in range(n_cu):
+                inside = i < min(exclude, n_cu - 1)
+                if inside == only:
+                    words[i // 32] |= 1 << (i % 32)
             st = ctypes.c_void_p()
             with torch.cuda.device(self.device):
                 rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(words), words)
             if rc != 0:
                 raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {rc}")
-            cache[exclude] = torch.cuda.ExternalStream(st.value, device=self.device)
-        return cache[exclude]
+            cache[key] = torch.cuda.ExternalStream(st.value, device=self.device)
+        return cache[key]
 
     def _token2wav(self, inputs, out, n_tok, speed):
         B = len(inputs)

@@ -190,16 +190,17 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
 
 // 256x256x32 tile, 8 waves as 2 (M) x 4 (N), each wave 128x64 = 4x2 accumulators of v_mfma_f32_32x32x16_bf16,
 // operands copied global -> LDS by the DMA path (global_load_lds, 16 B per lane, no staging registers) into a ring of
-// four 32 KB stages that runs three K steps ahead.
+// three 32 KB stages that runs two K steps ahead (a fourth stage measured no faster end to end and leaves less LDS for
+// the LM's kernels that share the CUs in the pipelined benchmark).
 // Why this shape (measured on MI355X with tests/micro/gemm_bench at the DiT shapes, M = 6400): operand fetches take
 // ~1.5 us to land while every CU streams, so a CU's MFMA rate is (bytes it keeps in flight) x (flops per byte of tile)
 // / latency.  The 128x128x64 tile with one step of lookahead keeps 32 KB in flight per workgroup (K step 2.7k cycles
-// against 512 of MFMA); this ring keeps 96 KB in flight at twice the flops per byte.
+// against 512 of MFMA); this ring keeps 64 KB in flight at twice the flops per byte.
 // The DMA writes a wave-instruction's 64 x 16 bytes linearly (16 rows of 64 B), so rows carry no padding; bank conflicts
 // are avoided by an XOR swizzle applied to the SOURCE chunk each lane fetches and to the fragment reads: chunk c of
-// row r lives at slot c ^ ((r >> 2) & 3).  Counted s_waitcnt vmcnt(8) + raw s_barrier keep two stages in flight across
+// row r lives at slot c ^ ((r >> 2) & 3).  Counted s_waitcnt vmcnt(4) + raw s_barrier keep a stage in flight across
 // the barrier (__syncthreads() would drain them).
-#define G2_STAGES 4
+#define G2_STAGES 3
 #define G2_BK 32
 #define G2_STAGE_BYTES (2 * 256 * G2_BK * 2)                // A tile + B tile, 256 rows x 32 bf16 each
 
