@@ -124,3 +124,55 @@ def test_tts_stream_against_reference(tag, case):
     want = f[f"e2e.c{ctag}.chunk0.samples"][early]
     note("parity_stream.json", f"tts_stream.{tag}.first10frames_maxerr", float(np.abs(got - want).max()))
     assert np.abs(got - want).max() < 3e-2          # measured 1.9e-2 (full size), 1.9e-3 (reduced size)
+
+
+def test_hift_chunked_equals_whole():
+    """The reference's own self-consistency script (hifigan/generator.py:728-746) on the engine, full size: the vocoder run
+    on growing prefixes (chunk 30 frames, 8 frames of context, finalize only on the last) reproduces the whole-utterance
+    waveform - the model is causal, and the kernels' tiles are anchored at frame 0, so the arithmetic per sample is the same."""
+    from fangyan_tts_amd.hift import HiftEngine
+    cfg = HiftCfg()
+    sd = synth.state_dict_torch(cfg.manifest(), DEV)
+    max_len, chunk, ctx = 300, 30, 8
+    eng = HiftEngine(sd, cfg, max_batch=1, max_frames=max_len, device=DEV)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    mel = torch.rand(1, 80, max_len, generator=g).to(DEV)
+    ri = torch.from_numpy(synth.hift_rand_ini()).to(DEV)
+    sn = torch.from_numpy(synth.hift_sine_noise(max_len * 480)).to(DEV)
+    for mode, flags, tol in (("direct", 2, 1e-5), ("bf16", 0, 1e-5)):
+        gt, _ = eng.inference(mel, ri, sn, flags=flags)
+        worst = 0.0
+        for i in range(0, max_len, chunk):
+            fin = i + chunk + ctx >= max_len
+            n_in = min(i + chunk + ctx, max_len)
+            w, _ = eng.inference(mel[:, :, :n_in].contiguous(), ri, sn, flags=flags, finalize=fin)
+            n_out = (n_in if fin else n_in - 8) * 480
+            worst = max(worst, maxerr(w[:, i * 480: n_out], gt[:, i * 480: n_out]))
+        note("parity_stream.json", f"hift.chunked_vs_whole.{mode}", worst)
+        assert worst <= tol, (mode, worst)
+
+
+def test_flow_chunked_equals_whole():
+    """The reference's flow self-consistency script (flow/flow.py:405-432), full size: with the chunk attention mask the mel
+    of the tokens seen so far does not change when more tokens follow."""
+    from fangyan_tts_amd.flow import FlowEngine
+    cfg = FlowCfg()
+    sd = synth.state_dict_torch(cfg.manifest(), DEV)
+    chunk, ctx = 50, cfg.pre_lookahead                       # static_chunk_size is in mel frames (50); the script steps 50 TOKENS
+    max_len = 4 * chunk
+    eng = FlowEngine(sd, cfg, max_batch=1, max_frames=2 * (max_len + chunk), device=DEV)
+    token = torch.from_numpy(synth.randint("in.flow.token.cons", (1, max_len), 0, cfg.vocab))
+    ptoken = torch.from_numpy(synth.randint("in.flow.ptoken.cons", (1, chunk), 0, cfg.vocab))
+    pfeat = torch.from_numpy(synth_mel("in.flow.pfeat.cons", 2 * chunk))
+    emb = torch.from_numpy(synth.normal("in.flow.spk", (1, cfg.spk_in)))
+    noise = torch.from_numpy(synth.flow_rand_noise(2 * (max_len + chunk)))
+    gt = eng.inference(token, [max_len], ptoken, [chunk], pfeat, [2 * chunk], emb, noise, streaming=True, finalize=True)
+    worst = 0.0
+    for i in range(0, max_len, chunk):
+        fin = i + chunk + ctx >= max_len
+        n_in = min(i + chunk + ctx, max_len)
+        m = eng.inference(token[:, :n_in].contiguous(), [n_in], ptoken, [chunk], pfeat, [2 * chunk], emb, noise, streaming=True, finalize=fin)
+        n_out = 2 * (n_in if fin else n_in - ctx)
+        worst = max(worst, maxerr(m[:, :, 2 * i: n_out], gt[:, :, 2 * i: n_out]))
+    note("parity_stream.json", "flow.chunked_vs_whole", worst)
+    assert worst <= 1e-5, worst                              # measured 0.0: rows and key tiles are anchored at frame 0
