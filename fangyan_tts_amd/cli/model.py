@@ -272,6 +272,7 @@ class CosyVoice3Model:
         if source_speech_token.shape[1] != 0:
             raise NotImplementedError("voice conversion (inference_vc) is not part of this build")
         if stream:
+            assert speed == 1.0, "speed change only support non-stream inference mode"      # cli/model.py:436
             yield from self._tts_stream(dict(text=text, prompt_text=prompt_text, llm_prompt_speech_token=llm_prompt_speech_token,
                                              flow_prompt_speech_token=flow_prompt_speech_token,
                                              prompt_speech_feat=prompt_speech_feat, flow_embedding=flow_embedding))
