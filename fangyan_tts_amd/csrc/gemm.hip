@@ -6,7 +6,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
 #define GM_BM 128
-int gemm_tile_override = 0;        // 0 auto; 128 / 64 force the register-staged kernel with that M tile (microbenchmarks)
+int gemm_tile_override = 0;        // microbenchmarks: 0 auto; 128 / 64 register-staged kernel with that M tile; 2 ring kernel, 256x128 tiles
 #define GM_BN 128
 #define GM_BK 64
 #define GM_PITCH 72          // bf16 elements per LDS row: 64 + 8 pad (144 B: 16-B aligned, spreads ds_read_b128 over banks)
@@ -200,83 +200,91 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
 // are avoided by an XOR swizzle applied to the SOURCE chunk each lane fetches and to the fragment reads: chunk c of
 // row r lives at slot c ^ ((r >> 2) & 3).  Counted s_waitcnt vmcnt(4) + raw s_barrier keep a stage in flight across
 // the barrier (__syncthreads() would drain them).
-#define G2_STAGES 3
 #define G2_BK 32
-#define G2_STAGE_BYTES (2 * 256 * G2_BK * 2)                // A tile + B tile, 256 rows x 32 bf16 each
+#define G2_RING_BYTES (96 * 1024)                            // three 32 KB stages (BN 256) or four 24 KB stages (BN 128)
 
-template <int EPI>
+// BN = 256: 8 waves as 2 (M) x 4 (N), 128x64 per wave.  BN = 128: 4 x 2 waves of 64x64 - twice the tiles for the N = 1024
+// products, which would leave most CUs idle at 256 columns per tile.
+template <int EPI, int BN>
 __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
     extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
     char* smem = reinterpret_cast<char*>(gm_smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 2, wn = wid & 3, lr = lane & 31, kh = lane >> 5;
+    constexpr int WN = BN / 64, WM = 8 / WN, MI = 256 / WM / 32;          // waves along N / M, 32-row tiles per wave
+    constexpr int STAGE = (256 + BN) * G2_BK * 2, STAGES = G2_RING_BYTES / STAGE, NB = BN / 128;   // NB: B DMAs per wave and stage
+    const int wm = wid / WN, wn = wid % WN, lr = lane & 31, kh = lane >> 5;
     // XCD-aware tile order (see gemm_bf16_k)
-    const int ntn = N / 256, nwg = gridDim.x;
+    const int ntn = N / BN, nwg = gridDim.x;
     const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int m0 = (wg / ntn) * 256, n0 = (wg % ntn) * 256;
+    const int m0 = (wg / ntn) * 256, n0 = (wg % ntn) * BN;
 
     // wave-instruction i (of 2) of wave wid fills stage bytes [(wid*2+i)*1024, +1024) of the A (and B) tile:
     // row = (wid*2+i)*16 + lane/4, slot = lane%4  ->  logical chunk = slot ^ ((row >> 2) & 3)
     const bf16_t* a_src[2];
-    const bf16_t* b_src[2];
+    const bf16_t* b_src[NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wid * 2 + i) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
         a_src[i] = A + (long)min(m0 + row, M - 1) * lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int row = (wid * NB + i) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
         b_src[i] = W + (long)min(n0 + row, N - 1) * K + c * 8;
     }
     auto issue = [&](int t) {
-        char* st = smem + (t % G2_STAGES) * G2_STAGE_BYTES + wid * 2048;
+        char* st = smem + (t % STAGES) * STAGE;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(a_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(a_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + wid * 2048 + i * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(b_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + 16384 + i * 1024), 16, 0, 0);
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds((const void*)(b_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + 16384 + wid * NB * 1024 + i * 1024), 16, 0, 0);
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     // fragment read offsets inside a stage (bytes): row*64 + ((2ks + kh) ^ ((row>>2)&3))*16
-    int a_off[4], b_off[2], a_sw[4], b_sw[2];
+    int a_off[MI], b_off[2], a_sw[MI], b_sw[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { const int ra = wm * 128 + i * 32 + lr; a_off[i] = ra * 64; a_sw[i] = (ra >> 2) & 3; }
+    for (int i = 0; i < MI; ++i) { const int ra = wm * (MI * 32) + i * 32 + lr; a_off[i] = ra * 64; a_sw[i] = (ra >> 2) & 3; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) { const int rb = wn * 64 + i * 32 + lr; b_off[i] = 16384 + rb * 64; b_sw[i] = (rb >> 2) & 3; }
 
     const int nt = K / G2_BK;
 #pragma unroll
-    for (int t = 0; t < G2_STAGES - 1; ++t)
+    for (int t = 0; t < STAGES - 1; ++t)
         if (t < nt) issue(t);
     for (int t = 0; t < nt; ++t) {
-        // stage t has landed once at most the stages issued after it are still outstanding (4 DMAs per stage per wave)
-        const int ahead = min(nt - 1 - t, G2_STAGES - 2);
-        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F78);        // vmcnt(8)
-        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F74);   // vmcnt(4)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0)
+        // stage t has landed once at most the stages issued after it are still outstanding (2 + NB DMAs per stage per wave)
+        const int ahead = min(nt - 1 - t, STAGES - 2);
+        constexpr int D = 2 + NB;
+        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * D));   // vmcnt(2 D): D <= 4, so the count fits the low four bits
+        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | D);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
         __builtin_amdgcn_s_barrier();                               // everyone's part of stage t is in LDS; the slot of stage t-1 is free
-        if (t + G2_STAGES - 1 < nt) issue(t + G2_STAGES - 1);
-        const char* sb = smem + (t % G2_STAGES) * G2_STAGE_BYTES;
-        frag_ab fa[2][4], fb[2][2];
-        auto load_frags = [&](int ks, frag_ab (&a)[4], frag_ab (&b)[2]) {
+        if (t + STAGES - 1 < nt) issue(t + STAGES - 1);
+        const char* sb = smem + (t % STAGES) * STAGE;
+        frag_ab fa[2][MI], fb[2][2];
+        auto load_frags = [&](int ks, frag_ab (&a)[MI], frag_ab (&b)[2]) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const frag_ab*>(sb + b_off[ni] + (((2 * ks + kh) ^ b_sw[ni]) << 4));
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const frag_ab*>(sb + a_off[mi] + (((2 * ks + kh) ^ a_sw[mi]) << 4));
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *reinterpret_cast<const frag_ab*>(sb + a_off[mi] + (((2 * ks + kh) ^ a_sw[mi]) << 4));
         };
         load_frags(0, fa[0], fb[0]);
 #pragma unroll
         for (int ks = 0; ks < G2_BK / 16; ++ks) {
             if (ks + 1 < G2_BK / 16) load_frags(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mi], fb[ks & 1][ni], acc[mi][ni], 0, 0, 0);
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     if (e.bias) bv = *reinterpret_cast<const float4*>(e.bias + n);
     if (EPI == 3) gv = *reinterpret_cast<const float4*>(e.gate + n);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
 #pragma unroll
         for (int it = 0; it < 8; ++it) vr[it] = make_float4(vq[it][0], vq[it][1], vq[it][2], vq[it][3]);
         __builtin_amdgcn_wave_barrier();                         // the next quarter overwrites the park region
-        const int mb = m0 + wm * 128 + mi * 32 + rsub;
+        const int mb = m0 + wm * (MI * 32) + mi * 32 + rsub;
         float4 old[8];
         if (EPI == 3) {
 #pragma unroll
@@ -343,16 +351,16 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     }
 }
 
-template <int EPI>
+template <int EPI, int BN>
 static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = (size_t)G2_STAGES * G2_STAGE_BYTES;
+    const size_t lds = (size_t)G2_RING_BYTES;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((N / 256) * cdiv(M, 256));
-    hipLaunchKernelGGL((gemm256_k<EPI>), grid, dim3(512), lds, st, A, lda, W, M, N, K, epi);
+    dim3 grid((N / BN) * cdiv(M, 256));
+    hipLaunchKernelGGL((gemm256_k<EPI, BN>), grid, dim3(512), lds, st, A, lda, W, M, N, K, epi);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -376,10 +384,23 @@ static int gemm_launch3(const void* A, int lda, const bf16_t* W, int M, int N, i
 template <bool PRECISE, int EPI>
 static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     if (gemm_tile_override == 64) return gemm_launch3<PRECISE, EPI, 64>(A, lda, W, M, N, K, epi, st);
-    // 256x256 tiles pay ~10 us of prologue / epilogue bursts per tile and leave CUs idle on small grids: measured on
-    // MI355X they win once there are >= ~160 of them (M 6400: N 2048 44 vs 59 us, N 3072 71 vs 72 us, N 1024 35 vs 27 us)
-    if (!PRECISE && gemm_tile_override != 128 && N % 256 == 0 && K % G2_BK == 0 && (N / 256) * cdiv(M, 256) >= 160)
-        return gemm_launch_256<EPI>((const bf16_t*)A, lda, W, M, N, K, epi, st);
+    // The LDS-DMA ring kernels pay ~10 us of prologue / epilogue bursts per tile, so what decides between them is how
+    // evenly their tiles fill the CUs: 256x256 tiles are ~15 % faster inside the K loop, 256x128 tiles come in twice the
+    // number.  Measured on MI355X at M = 6400 (us; register-staged 128x128x64 / ring 256x256 / ring 256x128):
+    //   N 3072 K 1024: 66 / 72 / 64    N 2048 K 1024: 58 / 44 / 48    N 1024 K 1024: 32 / 38 / 27    N 1024 K 2048: 49 / 61 / 42
+    if (!PRECISE && gemm_tile_override != 128 && N % 128 == 0 && K % G2_BK == 0) {
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t p;
+            cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+        }
+        const int t256 = N % 256 == 0 ? (N / 256) * cdiv(M, 256) : 0, t128 = (N / 128) * cdiv(M, 256);
+        auto fill = [&](int tiles) { return tiles ? (double)tiles / ((double)cdiv(tiles, cus) * cus) : 0.0; };
+        const double e256 = 1.15 * fill(t256), e128 = fill(t128);
+        if (gemm_tile_override != 2 && e256 >= e128 && e256 >= 0.5) return gemm_launch_256<EPI, 256>((const bf16_t*)A, lda, W, M, N, K, epi, st);
+        if (e128 >= 0.5 || gemm_tile_override == 2) return gemm_launch_256<EPI, 128>((const bf16_t*)A, lda, W, M, N, K, epi, st);
+    }
     return gemm_launch3<PRECISE, EPI, 128>(A, lda, W, M, N, K, epi, st);
 }
 
