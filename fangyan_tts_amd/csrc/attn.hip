@@ -91,36 +91,59 @@ __global__ __launch_bounds__(AT_NW * 64) void dit_attention_k(const bf16_t* __re
                 sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kt], 0, 0, 0);
             }
         }
-        float mx = -1e30f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                const float v = key < lim ? sc[kt][r] * scale_log2 : -1e30f;
-                sc[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - mnew);
-        float ps = 0.f;
         frag_ab pf[2][2];                                    // P^T as the B operand: [kt][k-step s] = registers 8s .. 8s+7
+        float alpha, ps = 0.f;
+        if (chunk == 0 && k0 + 64 <= len) {
+            // every key of the tile is visible to every query: no masks, the scale rides in the exponent's fma
+            float mx = sc[0][0];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = sc[kt][r] > -1e29f ? exp2f(sc[kt][r] - mnew) : 0.f;
-                ps += p;
-                pf[kt][r >> 3][r & 7] = (__bf16)p;
-            }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * scale_log2;
+            const float mnew = fmaxf(m_run, mx);
+            alpha = __builtin_amdgcn_exp2f(m_run - mnew);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], scale_log2, -mnew));
+                    ps += p;
+                    pf[kt][r >> 3][r & 7] = (__bf16)p;
+                }
+            m_run = mnew;
+        } else {
+            float mx = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                    const float v = key < lim ? sc[kt][r] * scale_log2 : -1e30f;
+                    sc[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(m_run, mx);
+            alpha = __builtin_amdgcn_exp2f(m_run - mnew);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = sc[kt][r] > -1e29f ? __builtin_amdgcn_exp2f(sc[kt][r] - mnew) : 0.f;
+                    ps += p;
+                    pf[kt][r >> 3][r & 7] = (__bf16)p;
+                }
+            m_run = mnew;
+        }
         ps += __shfl_xor(ps, 32, 64);
         l_run = l_run * alpha + ps;
-        m_run = mnew;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {     // the running maximum settles after a few tiles
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
         // O^T += V^T P^T
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
