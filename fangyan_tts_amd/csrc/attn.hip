@@ -13,7 +13,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 #define AT_D 64
 #define AT_KP 72             // bf16 elements per LDS row of the K tile (64 + 8 pad: conflict-free ds_read_b128 rows)
 #define AT_VP 96             // V tile pitch: 48 dwords, so the four rows of a transposed 4x16 block sit 16 banks apart
-#define AT_NW 2              // waves per workgroup, 32 queries each
+#define AT_NW 4              // waves per workgroup, 32 queries each
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -26,8 +26,8 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // qkv: bf16 [nseq*Tmax][3*H*64] as [q | k | v]; out: bf16 [nseq*Tmax][H*64]
 __global__ __launch_bounds__(AT_NW * 64) void dit_attention_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                               const int* __restrict__ seq_len, int Tmax, int H, int chunk, float scale_log2) {
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * AT_KP];
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * AT_VP];
+    __shared__ __attribute__((aligned(16))) bf16_t Kbuf[2][64 * AT_KP];      // two tiles: the next one is written while this one is read,
+    __shared__ __attribute__((aligned(16))) bf16_t Vbuf[2][64 * AT_VP];      // one barrier per key tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (AT_NW * 32);
     const int len = seq_len[s];
@@ -68,17 +68,24 @@ __global__ __launch_bounds__(AT_NW * 64) void dit_attention_k(const bf16_t* __re
     // receives column (lane & 15) of its four keys
     const int gi = lane >> 4, li = lane & 15;
     const int v_off = (4 * hf + (li >> 2)) * AT_VP + 16 * (gi & 1) + 4 * (li & 3);
-    load_kv(0);
-    for (int k0 = 0; k0 < kend; k0 += 64) {
-        __syncthreads();
+    auto store_kv = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int idx = tid + i * (AT_NW * 64), key = idx >> 3, dc = (idx & 7) * 8;
-            *reinterpret_cast<uint4*>(Ks + key * AT_KP + dc) = kreg[i];
-            *reinterpret_cast<uint4*>(Vs + key * AT_VP + dc) = vreg[i];
+            *reinterpret_cast<uint4*>(Kbuf[buf] + key * AT_KP + dc) = kreg[i];
+            *reinterpret_cast<uint4*>(Vbuf[buf] + key * AT_VP + dc) = vreg[i];
         }
-        __syncthreads();
-        if (k0 + 64 < kend) load_kv(k0 + 64);
+    };
+    const bool wave_live = q0 + wid * 32 < len;              // a wave past the sequence end only helps staging
+    load_kv(0);
+    store_kv(0);
+    __syncthreads();
+    for (int k0 = 0, it = 0; k0 < kend; k0 += 64, ++it) {
+        const bf16_t* Ks = Kbuf[it & 1];
+        const bf16_t* Vs = Vbuf[it & 1];
+        const bool more = k0 + 64 < kend;
+        if (more) load_kv(k0 + 64);
+        if (wave_live) {
         // S^T: sc[kt][r] = score of key k0 + 32kt + (r&3) + 8(r>>2) + 4hf against this lane's query
         f32x16 sc[2];
 #pragma unroll
@@ -157,6 +164,9 @@ __global__ __launch_bounds__(AT_NW * 64) void dit_attention_k(const bf16_t* __re
                     bf16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(frag_ab, vv), pf[kt][st], o[dt], 0, 0, 0);
                 }
+        }
+        if (more) store_kv((it + 1) & 1);                    // that buffer was last read before the previous barrier
+        __syncthreads();
     }
     if (qrow >= len) return;
     const float inv = 1.f / l_run;
