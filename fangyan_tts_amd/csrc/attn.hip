@@ -24,7 +24,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // product follows the accumulator's register order (key 16s + 8(j>>2) + 4h + (j&3) in element j of lane half h); the
 // A operand V^T is read to match, transposed by the LDS itself (ds_read_b64_tr_b16 on the row-major V tile).
 // qkv: bf16 [nseq*Tmax][3*H*64] as [q | k | v]; out: bf16 [nseq*Tmax][H*64]
-__global__ __launch_bounds__(AT_NW * 64) void dit_attention_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void dit_attention_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                               const int* __restrict__ seq_len, int Tmax, int H, int chunk, float scale_log2) {
     __shared__ __attribute__((aligned(16))) bf16_t Kbuf[2][64 * AT_KP];      // two tiles: the next one is written while this one is read,
     __shared__ __attribute__((aligned(16))) bf16_t Vbuf[2][64 * AT_VP];      // one barrier per key tile
