@@ -110,7 +110,8 @@ class CosyVoice3Model:
         n_prod = len(self.llms)
         if flow_cu_exclude is None:
             flow_cu_exclude = 80 if n_prod == 1 else 0
-        s_fv = self._masked_stream(flow_cu_exclude) if flow_cu_exclude > 0 else torch.cuda.Stream(device=dev)
+        prio = [int(v) for v in os.environ.get("FY_PIPE_PRIO", "0,0").split(",")]      # stream priorities LM, flow: equal measured best (89.1 ms/step; LM high 89.9; flow high 125)
+        s_fv = self._masked_stream(flow_cu_exclude) if flow_cu_exclude > 0 else torch.cuda.Stream(device=dev, priority=prio[1])
         qs = [queue.Queue(maxsize=2 * self.lm_group) for _ in range(n_prod)]
         z = torch.zeros(1, 0, dtype=torch.int32)
 
@@ -118,7 +119,7 @@ class CosyVoice3Model:
             llm, q = self.llms[pi], qs[pi]
             try:
                 lm_stream = self._masked_stream(flow_cu_exclude, only=True, tag=pi) if (flow_cu_exclude > 0 and lm_isolate) else \
-                    torch.cuda.Stream(device=dev, priority=-1)
+                    torch.cuda.Stream(device=dev, priority=prio[0])
                 with torch.cuda.device(dev), torch.cuda.stream(lm_stream):
                     G = self.lm_group
                     for g0 in range(pi * G, len(batches), n_prod * G):
