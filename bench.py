@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
-    ap.add_argument("--llm-streams", type=int, default=2, help="LM handles decoding different steps' batches concurrently")
+    ap.add_argument("--llm-streams", type=int, default=3, help="LM handles decoding different steps' batches concurrently")
     ap.add_argument("--lm-isolate", action="store_true", help="LM streams run ONLY on the CUs the flow stream is kept off")
     ap.add_argument("--lm-group", type=int, default=1, help="consecutive steps whose LM decode runs as one call")
     ap.add_argument("--flow-cu-exclude", type=int, default=None, help="CUs kept clear of the flow / vocoder stream")
