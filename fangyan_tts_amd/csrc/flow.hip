@@ -169,19 +169,6 @@ __global__ __launch_bounds__(256) void ln_mod_k(const float* __restrict__ h, con
     }
 }
 
-// x-transformers apply_rotary_pos_emb on the un-split q and k (modules.py:368-373): only channels
-// 0..rot-1 (= head 0) rotate, in interleaved pairs.  qkv bf16 [M][3*inner], in place.
-__global__ void dit_rope_k(bf16_t* __restrict__ qkv, const float2* __restrict__ tab, const int* __restrict__ seq_len, int Tmax, int inner, int half) {
-    int s = blockIdx.y, t = blockIdx.x, i = threadIdx.x;      // i < 2*half: q pairs then k pairs
-    if (t >= seq_len[s] || i >= 2 * half) return;
-    int which = i / half, pr = i % half;
-    bf16_t* p = qkv + ((long)s * Tmax + t) * 3 * inner + which * inner + 2 * pr;
-    float a = bf16_to_f32(p[0]), b = bf16_to_f32(p[1]);
-    float2 cs = tab[(long)t * half + pr];
-    p[0] = f32_to_bf16(a * cs.x - b * cs.y);
-    p[1] = f32_to_bf16(b * cs.x + a * cs.y);
-}
-
 // CFG mix and Euler update, flow_matching.py:114-118
 __global__ void euler_k(float* __restrict__ x, const float* __restrict__ v, const int* __restrict__ T, int Tmax, int C, float dt, float cfg) {
     int b = blockIdx.y, t = blockIdx.x, c = threadIdx.x;
@@ -416,8 +403,10 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
         hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + D, m, f->xn, M, D);
         GemmEpi q;
         q.bias = k.bqkv; q.out = f->qkv; q.out_bf16 = 1; q.ldc = 3 * inner;
+        // x-transformers rotary embedding (head 0 of q and k only, modules.py:368-373) in the projection's epilogue, on the fp32
+        // sums before they are rounded to bf16
+        q.rope = f->rope; q.rope_T = Tmax; q.rope_half = c.head_dim / 2; q.rope_stride = inner;
         FY_TRY(gemm_bf16(f->xn, D, k.wqkv, M, 3 * inner, D, q, st));
-        hipLaunchKernelGGL(dit_rope_k, dim3(Tmax, nseq), dim3(64), 0, st, f->qkv, f->rope, f->seq_len, Tmax, inner, c.head_dim / 2);
         FY_TRY(dit_attention(f->qkv, f->ao, f->seq_len, nseq, Tmax, c.heads, streaming ? c.static_chunk : 0, st));
         GemmEpi o;
         o.mode = EPI_GATE_RESID; o.bias = k.bo; o.resid = f->h; o.gate = m + 2 * D; o.ldc = D;

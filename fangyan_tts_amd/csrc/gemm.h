@@ -20,6 +20,10 @@ struct GemmEpi {
     // EPI_GATE_RESID: resid[m][n] += gate[n] * (acc + bias[n]) for rows with row_ok[m] != 0 (null = all)
     float* resid = nullptr;
     const float* gate = nullptr;
+    // EPI_STORE to bf16, optional: rotary embedding of the interleaved pairs of columns [0, 2*rope_half) and
+    // [rope_stride, rope_stride + 2*rope_half) at position (row % rope_T), table [rope_T][rope_half] of (cos, sin)
+    const float2* rope = nullptr;
+    int rope_T = 0, rope_half = 0, rope_stride = 0;
 };
 
 extern int gemm_tile_override;     // microbenchmarks: 0 auto; 128 / 64 register-staged kernel with that M tile; 2 ring kernel, 256x128 tiles

@@ -24,6 +24,17 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+// x-transformers apply_rotary_pos_emb on four consecutive output columns starting at n (two interleaved pairs)
+__device__ __forceinline__ void epi_rope(float4& v, const GemmEpi& e, int m, int n) {
+    int nn = n >= e.rope_stride ? n - e.rope_stride : n;
+    if (n >= 2 * e.rope_stride || nn >= 2 * e.rope_half) return;
+    const float2* tab = e.rope + (long)(m % e.rope_T) * e.rope_half + (nn >> 1);
+    const float2 c0 = tab[0], c1 = tab[1];
+    const float a = v.x, b = v.y, c = v.z, d = v.w;
+    v.x = a * c0.x - b * c0.y; v.y = b * c0.x + a * c0.y;
+    v.z = c * c1.x - d * c1.y; v.w = d * c1.x + c * c1.y;
+}
+
 // Epilogue shared by the GEMM kernels, through LDS: the accumulator layout (column on the lane, rows in registers)
 // would store 2-4 bytes per lane; each wave instead parks its 64x64 tile in LDS (the operand buffers are free by now)
 // and reads it back row-wise, so every lane moves 4 consecutive columns: 16 wide stores per lane instead of 64 narrow ones.
@@ -75,6 +86,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], bf16_t* gm_sm
             *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
         } else {
             if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
+            if (EPI == 0 && e.rope) epi_rope(v, e, m, n);
             uint2 pk;
             pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
             pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
@@ -342,6 +354,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
                 *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
             } else {
                 if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
+                if (EPI == 0 && e.rope) epi_rope(v, e, m, n);
                 uint2 pk;
                 pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
                 pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
@@ -421,6 +434,8 @@ static int gemm_check(const void* A, int lda, const bf16_t* W, int M, int N, int
     FY_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && (lda * a_elem) % 16 == 0, FY_ERR_ARG, "gemm: operands must be 16-B aligned");
     FY_CHECK(e.ldc >= N && ((e.mode == EPI_STORE && e.out) || (e.mode == EPI_GATE_RESID && e.resid && e.gate)), FY_ERR_ARG, "gemm: bad epilogue");
     FY_CHECK(N % 4 == 0 && e.ldc % 4 == 0, FY_ERR_ARG, "gemm: N and the output pitch must be multiples of 4 (N %d, ldc %d)", N, e.ldc);
+    FY_CHECK(!e.rope || (e.mode == EPI_STORE && e.out_bf16 && e.act == ACT_NONE && e.rope_T >= 1 && e.rope_half >= 2 && e.rope_half % 2 == 0 &&
+                         e.rope_stride >= 2 * e.rope_half), FY_ERR_ARG, "gemm: bad rotary epilogue");
     return FY_OK;
 }
 
