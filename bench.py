@@ -149,6 +149,7 @@ def main():
         samples = run(a.warmup)
         torch.cuda.synchronize()
         log(f"{a.warmup} warmup steps done")
+    L = _lib.lib()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -158,6 +159,18 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    # roofline: the same K pipelined steps once more with HIP events around every launch of the dominant kernels (the DiT
+    # linears) on the stream they are launched on.  Not in the timed pass itself: the 1800 event records per step cost
+    # the flow stream ~6 % (88.5 against 83 ms per step); only that name is recorded, so the LM threads pay nothing.
+    L.fy_prof_reset()
+    L.fy_prof_only(b"gemm_bf16")
+    L.fy_prof_enable(1)
+    run(a.steps)
+    torch.cuda.synchronize()
+    L.fy_prof_enable(0)
+    L.fy_prof_only(None)
+    ms_t, flops_t, n_t = _lib.prof_get("gemm_bf16")
+    L.fy_prof_reset()
     if world > 1:
         t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -172,8 +185,7 @@ def main():
     torch.cuda.synchronize()
     latency_ms = 1e3 * (time.perf_counter() - t1)
 
-    # roofline leg: one more step with HIP events around every launch of the dominant kernel
-    L = _lib.lib()
+    # one more step alone with every profiled stage recorded (stage_ms_per_step below)
     L.fy_prof_reset()
     L.fy_prof_enable(1)
     step()
@@ -181,7 +193,7 @@ def main():
     L.fy_prof_enable(0)
     prof = {k: _lib.prof_get(k) for k in ("gemm_bf16", "conv_mfma", "gemv")}
     L.fy_prof_reset()
-    ms, flops, n = prof["gemm_bf16"]
+    ms, flops, n = ms_t, flops_t, n_t // max(a.steps, 1)          # the timed region's launches
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     # HBM-side traffic per launch of the same kernel on the same shapes: PMC counters cannot be read from
     # inside this process, so the figure is the one rocprofv3 measured (profiles/r01_gemm_pmc.json says how)
@@ -191,9 +203,10 @@ def main():
     roofline = {"bound": "mfma", "kernel": "DiT linears: gemm256_k (LDS-DMA ring, 256x256x32 or 256x128x32 tiles by CU fill); gemm_bf16_k (128x128x64) for small grids", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_gemm_pmc.json)",
-                "launches_per_step": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
-                "gflop_per_launch": round(flops / max(n, 1) / 1e9, 3),
-                "stage_ms_per_step": {k: round(v[0], 3) for k, v in prof.items()}}
+                "launches_per_step": n, "avg_launch_us": round(1e3 * ms / max(n_t, 1), 2),
+                "gflop_per_launch": round(flops / max(n_t, 1) / 1e9, 3), "measured_over": "a repeat of the timed K pipelined steps with HIP events on the launch stream",
+                "achieved_one_step_alone": round(prof["gemm_bf16"][1] / (prof["gemm_bf16"][0] * 1e-3) / 1e12, 2) if prof["gemm_bf16"][0] > 0 else None,
+                "stage_ms_per_step_alone": {k: round(v[0], 3) for k, v in prof.items()}}
 
     out = {
         "metric": "synthesised audio sec/sec (RTF^-1) CosyVoice3-0.5B instruct, batch 8",

@@ -69,6 +69,8 @@ def _declare(L):
     vp, i32, u32, f32p, i32p = C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.POINTER(C.c_int32)
     L.fy_version.restype = C.c_int
     L.fy_prof_enable.argtypes = [C.c_int]
+    L.fy_prof_only.argtypes = [C.c_char_p]
+    L.fy_prof_only.restype = None
     L.fy_prof_enable.restype = None
     L.fy_prof_reset.restype = None
     L.fy_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]

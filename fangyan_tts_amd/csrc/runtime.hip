@@ -93,12 +93,14 @@ int transpose_blc_to_bcl(const float* src, float* dst, int B, int C, int L, long
 #include <mutex>
 struct ProfRec { std::string name; double work; hipEvent_t a, b; };
 static bool g_prof_on = false;
+static std::string g_prof_only;                  // when non-empty, only scopes of this name are recorded
 static std::vector<ProfRec> g_prof;
 static std::mutex g_prof_mu;
 
 ProfScope::ProfScope(const char* name, double work, hipStream_t s) : st(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_only.empty() && g_prof_only != name) return;
     ProfRec r;
     r.name = name; r.work = work;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
@@ -113,6 +115,11 @@ ProfScope::~ProfScope() {
 }
 
 extern "C" void fy_prof_enable(int on) { g_prof_on = on != 0; }
+
+extern "C" void fy_prof_only(const char* name) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_only = name ? name : "";
+}
 
 extern "C" void fy_prof_reset(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

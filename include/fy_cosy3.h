@@ -36,6 +36,7 @@ int fy_version(void);
  * names: "gemm_bf16" (DiT / projection GEMMs; work = flops), "conv_mfma" (work = flops),
  * "gemv" (LLM decode products; work = weight bytes).  Adds two event records per launch while on. */
 void fy_prof_enable(int on);
+void fy_prof_only(const char* name);   /* record only launches of this name (null: all) - keeps the cost off the other streams */
 void fy_prof_reset(void);
 int fy_prof_get(const char* name, double* total_ms, double* work, int64_t* count);
 
