@@ -193,7 +193,11 @@ def main():
     L.fy_prof_enable(0)
     prof = {k: _lib.prof_get(k) for k in ("gemm_bf16", "conv_mfma", "gemv")}
     L.fy_prof_reset()
-    ms, flops, n = ms_t, flops_t, n_t // max(a.steps, 1)          # the timed region's launches
+    # Two event-based figures for the DiT linears.  (1) A step alone: the interval between the two events of a launch is the
+    # kernel's own duration - it agrees with rocprofv3's average for the pipelined command (profiles/r01_bench_kernel_stats_
+    # final.csv: 48.6 us) - and is what `achieved` uses.  (2) The repeat of the timed pipelined steps: there the interval
+    # also contains the time the flow stream waits for CUs that the LM streams hold, so it is longer than the kernel ran.
+    ms, flops, n = prof["gemm_bf16"]
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     # HBM-side traffic per launch of the same kernel on the same shapes: PMC counters cannot be read from
     # inside this process, so the figure is the one rocprofv3 measured (profiles/r01_gemm_pmc.json says how)
@@ -203,9 +207,12 @@ def main():
     roofline = {"bound": "mfma", "kernel": "DiT linears: gemm256_k (LDS-DMA ring, 256x256x32 or 256x128x32 tiles by CU fill); gemm_bf16_k (128x128x64) for small grids", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_gemm_pmc.json)",
-                "launches_per_step": n, "avg_launch_us": round(1e3 * ms / max(n_t, 1), 2),
-                "gflop_per_launch": round(flops / max(n_t, 1) / 1e9, 3), "measured_over": "a repeat of the timed K pipelined steps with HIP events on the launch stream",
-                "achieved_one_step_alone": round(prof["gemm_bf16"][1] / (prof["gemm_bf16"][0] * 1e-3) / 1e12, 2) if prof["gemm_bf16"][0] > 0 else None,
+                "launches_per_step": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
+                "gflop_per_launch": round(flops / max(n, 1) / 1e9, 3),
+                "measured_over": "HIP events on the launch stream around every launch of one step run alone after the timed region",
+                "inside_pipelined_steps": {"stream_interval_us_per_launch": round(1e3 * ms_t / max(n_t, 1), 2),
+                                           "tflops_over_that_interval": round(flops_t / (ms_t * 1e-3) / 1e12, 2) if ms_t > 0 else None,
+                                           "note": "a repeat of the K timed steps; the interval includes waits for CUs held by the LM streams"},
                 "stage_ms_per_step_alone": {k: round(v[0], 3) for k, v in prof.items()}}
 
     out = {
