@@ -74,6 +74,13 @@ __device__ inline float act_snake(float x, float a) {
 __device__ inline float act_elu(float x) { return x > 0.f ? x : expm1f(x); }
 __device__ inline float act_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ inline float act_mish(float x) { return x * tanhf(act_softplus(x)); }
+// mish through one exponential: tanh(log(1 + e)) = n / (n + 2) with n = e (e + 2), e = exp(x)  (an identity; for results that
+// are rounded to bf16 next, hardware exp / rcp are ample)
+__device__ inline float act_mish_fast(float x) {
+    const float e = __expf(fminf(x, 20.f));
+    const float n = e * (e + 2.f);
+    return x * n * __builtin_amdgcn_rcpf(n + 2.f);
+}
 __device__ inline float act_silu(float x) { return x / (1.0f + expf(-x)); }
 // tanh-GELU on values that are rounded to bf16 next: tanh(u) = 1 - 2 / (exp(2u) + 1) with the hardware exp
 __device__ inline float act_gelu_tanh_fast(float x) {

@@ -388,10 +388,11 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), av = make_float4(1.f, 1.f, 1.f, 1.f);
     if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + co);
     if (ya) av = *reinterpret_cast<const float4*>(d.alpha_out + co);
-    // two instantiations: the plain one (no output activation, no reflect pad: every ResBlock conv) stays small --
+    // three instantiations: the plain one (no output activation, no reflect pad: every ResBlock conv) and the Mish one stay small --
     // the generic one carries the transcendental code of every activation kind at each of its 64 elements
-    auto epilogue = [&](auto generic_tag) {
-        constexpr bool GENERIC = decltype(generic_tag)::value;
+    auto epilogue = [&](auto kind_tag) {
+        constexpr int KIND = decltype(kind_tag)::value;      // 0 plain, 1 Mish only (the DiT position conv), 2 anything
+        constexpr bool GENERIC = KIND == 2;
     #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
     #pragma unroll
@@ -427,6 +428,10 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
                     v.x = apply_post(v.x, d.post_act, d.post_slope); v.y = apply_post(v.y, d.post_act, d.post_slope);
                     v.z = apply_post(v.z, d.post_act, d.post_slope); v.w = apply_post(v.w, d.post_act, d.post_slope);
                 }
+                if (KIND == 1) {
+                    if (PRECISE) { v.x = act_mish(v.x); v.y = act_mish(v.y); v.z = act_mish(v.z); v.w = act_mish(v.w); }
+                    else { v.x = act_mish_fast(v.x); v.y = act_mish_fast(v.y); v.z = act_mish_fast(v.z); v.w = act_mish_fast(v.w); }
+                }
                 if (p >= n_out || !col_live) continue;
                 float4 o;
                 o.x = fmaf(v.x + rv[it].x, osc, ov[it].x); o.y = fmaf(v.y + rv[it].y, osc, ov[it].y);
@@ -451,8 +456,9 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
             __builtin_amdgcn_wave_barrier();                     // the next half overwrites the parked tile
         }
     };
-    if (d.post_act == ACT_NONE && !d.reflect1) epilogue(std::false_type{});
-    else epilogue(std::true_type{});
+    if (d.post_act == ACT_NONE && !d.reflect1) epilogue(std::integral_constant<int, 0>{});
+    else if (d.post_act == ACT_MISH && !d.reflect1) epilogue(std::integral_constant<int, 1>{});
+    else epilogue(std::integral_constant<int, 2>{});
     DBG_T(5);
 }
 
