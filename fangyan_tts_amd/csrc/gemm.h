@@ -1,7 +1,7 @@
 // Dense products for the DiT estimator and the Qwen2 speech-token LM.
 //   gemm_bf16   : C[M,N] = A[M,K] * W[N,K]^T on v_mfma_f32_32x32x16_bf16, A and W both K-contiguous
-//                 (torch Linear layout), fused epilogues; 256x256x32 tiles fed by an LDS-DMA ring for the
-//                 wide products, 128x128x64 register-staged tiles otherwise (gemm.hip says when and why).
+//                 (torch Linear layout), fused epilogues; 256x128x32 tiles fed by an LDS-DMA ring, two workgroups
+//                 per CU, for grids that fill the chip, 128x128x64 register-staged tiles otherwise (gemm.hip says why).
 //   gemv_bf16w  : y[r,n] = sum_k W[n,k] x[r,k] for r <= 8 rows of fp32 activations against bf16 weights,
 //                 fp32-faithful on the matrix cores (exact 3-way bf16 split of the activations) - the
 //                 LLM decode product.
@@ -26,7 +26,7 @@ struct GemmEpi {
     int rope_T = 0, rope_half = 0, rope_stride = 0;
 };
 
-extern int gemm_tile_override;     // microbenchmarks: 0 auto; 128 / 64 register-staged kernel with that M tile; 2 ring kernel, 256x128 tiles
+extern int gemm_tile_override;     // microbenchmarks: 0 auto; 128 / 64 register-staged kernel with that M tile; 2 / 256 ring kernel with 256x128 / 256x256 tiles
 // A: bf16 [M][lda]; W: bf16 [N][K] (K % 64 == 0); M, N arbitrary
 int gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st);
 // A: fp32 [M][lda], split into bf16 hi + lo on the fly (fp32-class accuracy when W is bf16-exact)

@@ -6,7 +6,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
 #define GM_BM 128
-int gemm_tile_override = 0;        // microbenchmarks: 0 auto; 128 / 64 register-staged kernel with that M tile; 2 ring kernel, 256x128 tiles
+int gemm_tile_override = 0;        // microbenchmarks: 0 auto; 128 / 64 register-staged kernel with that M tile; 2 / 256 ring kernel with 256x128 / 256x256 tiles
 #define GM_BN 128
 #define GM_BK 64
 #define GM_PITCH 72          // bf16 elements per LDS row: 64 + 8 pad (144 B: 16-B aligned, spreads ds_read_b128 over banks)
@@ -213,17 +213,18 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
 // row r lives at slot c ^ ((r >> 2) & 3).  Counted s_waitcnt vmcnt(4) + raw s_barrier keep a stage in flight across
 // the barrier (__syncthreads() would drain them).
 #define G2_BK 32
-#define G2_RING_BYTES (96 * 1024)                            // three 32 KB stages (BN 256) or four 24 KB stages (BN 128)
+#define G2_RING_BYTES (96 * 1024)                            // BN 256: three 32 KB stages; BN 128: three 24 KB stages = 72 KB, so that two workgroups share a CU
 
-// BN = 256: 8 waves as 2 (M) x 4 (N), 128x64 per wave.  BN = 128: 4 x 2 waves of 64x64 - twice the tiles for the N = 1024
-// products, which would leave most CUs idle at 256 columns per tile.
+// BN = 256: 8 waves as 2 (M) x 4 (N), 128x64 per wave.  BN = 128: 4 x 2 waves of 64x64, <= 128 VGPRs and a 72 KB ring, so
+// two workgroups are resident per CU: one's prologue / epilogue bursts run under the other's K loop (the four DiT
+// products of a block: 184 -> 168 us), and the N = 1024 products get twice the tiles.
 template <int EPI, int BN>
 __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
     extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
     char* smem = reinterpret_cast<char*>(gm_smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int WN = BN / 64, WM = 8 / WN, MI = 256 / WM / 32;          // waves along N / M, 32-row tiles per wave
-    constexpr int STAGE = (256 + BN) * G2_BK * 2, STAGES = G2_RING_BYTES / STAGE, NB = BN / 128;   // NB: B DMAs per wave and stage
+    constexpr int STAGE = (256 + BN) * G2_BK * 2, STAGES = (BN == 128 ? 3 : G2_RING_BYTES / STAGE), NB = BN / 128;   // NB: B DMAs per wave and stage
     const int wm = wid / WN, wn = wid % WN, lr = lane & 31, kh = lane >> 5;
     // XCD-aware tile order (see gemm_bf16_k)
     const int ntn = N / BN, nwg = gridDim.x;
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
 template <int EPI, int BN>
 static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = (size_t)G2_RING_BYTES;
+    const size_t lds = BN == 128 ? (size_t)72 * 1024 : (size_t)G2_RING_BYTES;   // BN 128: two workgroups per CU
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -392,15 +393,18 @@ static int gemm_launch3(const void* A, int lda, const bf16_t* W, int M, int N, i
     return FY_OK;
 }
 
-// 256x128 tiles move 25 % fewer operand bytes per flop through L2 (the binding resource at these shapes); they
-// are used when they still fill the chip (>= 1 workgroup per CU) and the split operand of the precise form is off
+// Which kernel: the LDS-DMA ring with 256x128 tiles whenever its tiles cover most of the chip, the register-staged
+// 128x128x64 kernel for small grids and for the split operand of the precise form.
 template <bool PRECISE, int EPI>
 static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     if (gemm_tile_override == 64) return gemm_launch3<PRECISE, EPI, 64>(A, lda, W, M, N, K, epi, st);
-    // The LDS-DMA ring kernels pay ~10 us of prologue / epilogue bursts per tile, so what decides between them is how
-    // evenly their tiles fill the CUs: 256x256 tiles are ~15 % faster inside the K loop, 256x128 tiles come in twice the
-    // number.  Measured on MI355X at M = 6400 (us; register-staged 128x128x64 / ring 256x256 / ring 256x128):
-    //   N 3072 K 1024: 66 / 72 / 64    N 2048 K 1024: 58 / 44 / 48    N 1024 K 1024: 32 / 38 / 27    N 1024 K 2048: 49 / 61 / 42
+    // Measured on MI355X with tests/micro/gemm_bench (us; register-staged 128x128x64 / ring 256x256, one workgroup per CU /
+    // ring 256x128, two per CU):
+    //   M 6400:  N 3072 K 1024: 68 / 70 / 57    N 2048 K 1024: 58 / 42 / 42    N 1024 K 1024: 32 / 37 / 27    N 1024 K 2048: 48 / 62 / 42
+    //   M 12800: N 3072 K 1024: 119 / 115 / 97  N 2048 K 1024: 95 / 87 / 83    N 1024 K 1024: 47 / 38 / 38
+    //   M 3200:  N 3072 K 1024: 41 / 39 / 37    N 1024 K 1024: 21.6 / 36 / 22.8   N 1024 K 2048: 34 / 61 / 37   (104 tiles: too few)
+    // The 256x256 tile is ~15 % faster inside the K loop but never ahead overall: every tile pays ~10 us of prologue /
+    // epilogue bursts, which only a second resident workgroup hides; it stays selectable for the microbenchmark.
     if (!PRECISE && gemm_tile_override != 128 && N % 128 == 0 && K % G2_BK == 0) {
         static int cus = 0;
         if (!cus) {
@@ -408,11 +412,9 @@ static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, i
             hipDeviceProp_t p;
             cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
         }
-        const int t256 = N % 256 == 0 ? (N / 256) * cdiv(M, 256) : 0, t128 = (N / 128) * cdiv(M, 256);
-        auto fill = [&](int tiles) { return tiles ? (double)tiles / ((double)cdiv(tiles, cus) * cus) : 0.0; };
-        const double e256 = 1.15 * fill(t256), e128 = fill(t128);
-        if (gemm_tile_override != 2 && e256 >= e128 && e256 >= 0.5) return gemm_launch_256<EPI, 256>((const bf16_t*)A, lda, W, M, N, K, epi, st);
-        if (e128 >= 0.5 || gemm_tile_override == 2) return gemm_launch_256<EPI, 128>((const bf16_t*)A, lda, W, M, N, K, epi, st);
+        if (gemm_tile_override == 256 && N % 256 == 0) return gemm_launch_256<EPI, 256>((const bf16_t*)A, lda, W, M, N, K, epi, st);
+        const int t128 = (N / 128) * cdiv(M, 256);
+        if (gemm_tile_override == 2 || 5 * t128 >= 3 * cus) return gemm_launch_256<EPI, 128>((const bf16_t*)A, lda, W, M, N, K, epi, st);
     }
     return gemm_launch3<PRECISE, EPI, 128>(A, lda, W, M, N, K, epi, st);
 }
