@@ -99,6 +99,9 @@ def _declare(L):
     L.fy_llm_destroy.argtypes = [vp]
     L.fy_llm_destroy.restype = None
     L.fy_llm_generate.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, i32, vp, i32, vp, vp, u32, vp]
+    L.fy_mel_speed.argtypes = [vp, i32, i32, vp, i32, vp]
+    L.fy_llm_begin.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, i32, vp, i32, vp]
+    L.fy_llm_step.argtypes = [vp, i32, vp, i32, vp, vp, i32p, vp]
     L.fy_llm_logp.argtypes = [vp, i32, f32p, vp]
 
 

@@ -206,7 +206,7 @@ class CosyVoice3Model:
         frames = [2 * n for n in n_tok]
         if speed != 1.0:                                    # cli/model.py:435-437
             assert B == 1, "speed change only supports a single utterance"
-            mel = torch.nn.functional.interpolate(mel, size=int(mel.shape[2] / speed), mode="linear").contiguous()
+            mel = self.flow.speed(mel, speed)
             frames = [mel.shape[2]]
         wav, _ = self.hift.inference(mel, self.rand_ini, self.sine_noise, frames=frames)
         self.last_mel, self.last_frames = mel, frames        # kept for parity tests / debugging
@@ -220,9 +220,10 @@ class CosyVoice3Model:
         """The reference's chunk schedule: a chunk is cut whenever `hop + pre_lookahead` tokens beyond the offset exist (the
         first hop is padded so prompt + hop is a multiple of 25); every chunk re-runs the flow decoder over all tokens so far
         (chunk attention mask, finalize=False) and the vocoder over the whole mel so far (finalize=False), and yields the
-        samples beyond those already yielded; the last call is finalize=True without the chunk mask.  The chunk boundaries
-        depend only on the token count, so decoding the whole token sequence first (one device-side loop here) yields the
-        same chunks as the reference's polling loop."""
+        samples beyond those already yielded; the last call is finalize=True without the chunk mask.  The reference polls
+        a list its LM thread fills; here the LM is advanced on demand (`LlmEngine.begin` / `step`) by as many tokens as the
+        next chunk still lacks, so the first chunk leaves after hop + look-ahead tokens, not after the whole utterance.  The
+        chunk boundaries depend only on the token count, so the chunks are the reference's."""
         z = torch.zeros(1, 0, dtype=torch.int32)
         text = [d["text"].reshape(-1).tolist()]
         ptext = [d.get("prompt_text", z).reshape(-1).tolist()]
@@ -237,10 +238,8 @@ class CosyVoice3Model:
         up = self.cfg.hift.upsample_total
         with self.lock:
             self._arm_sampler()
-            out, out_n, _ = self.llm.generate(text, ptext, pspeech)
-            n = int(out_n.cpu()[0])
-            if n < 1:
-                raise RuntimeError("the language model emitted no speech token for an utterance")
+            out, _, _ = self.llm.begin(text, ptext, pspeech)
+            (n,), (done,) = self.llm.step(0)
             pad = -(-n_fp // hop0) * hop0 - n_fp
             offset, speech_offset, mel_all = 0, 0, None
 
@@ -255,12 +254,16 @@ class CosyVoice3Model:
                 return wav[:, speech_offset:end], mel_all, end
 
             while True:
-                hop = hop0 + pad if offset == 0 else hop0
-                if n - offset < hop + look:
+                need = offset + (hop0 + pad if offset == 0 else hop0) + look
+                while n < need and not done:                # the silent-token filter may drop tokens: ask again until enough
+                    (n,), (done,) = self.llm.step(need - n)
+                if n < need:
                     break
-                wav, mel_all, speech_offset = token2wav(offset + hop + look, offset, mel_all, speech_offset, True, False)
-                offset += hop
+                wav, mel_all, speech_offset = token2wav(need, offset, mel_all, speech_offset, True, False)
+                offset = need - look
                 yield {"tts_speech": wav.cpu()}
+            if n < 1:
+                raise RuntimeError("the language model emitted no speech token for an utterance")
             wav, mel_all, speech_offset = token2wav(n, offset, mel_all, speech_offset, False, True)
             self.last_mel, self.last_frames = mel_all, [mel_all.shape[2]]
             yield {"tts_speech": wav.cpu()}
@@ -272,6 +275,12 @@ class CosyVoice3Model:
             source_speech_token=torch.zeros(1, 0, dtype=torch.int32), stream=False, speed=1.0, **kwargs):
         if source_speech_token.shape[1] != 0:
             raise NotImplementedError("voice conversion (inference_vc) is not part of this build")
+        if not isinstance(text, torch.Tensor):
+            # A text *generator* sends the reference to Qwen2LM.inference_bistream (cli/model.py:104-111), which reads
+            # self.llm_embedding (llm/llm.py:545-546) - an attribute CosyVoice3LM.__init__ (llm.py:641-668) never creates, so
+            # for this model family the reference's LM thread dies with exactly this error and no audio is produced.
+            raise AttributeError("'CosyVoice3LM' object has no attribute 'llm_embedding' (streaming text input, "
+                                 "inference_bistream, does not work for CosyVoice3 in the reference either)")
         if stream:
             assert speed == 1.0, "speed change only support non-stream inference mode"      # cli/model.py:436
             yield from self._tts_stream(dict(text=text, prompt_text=prompt_text, llm_prompt_speech_token=llm_prompt_speech_token,

@@ -496,6 +496,25 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
 
 // The reference's estimator hand-off (flow_matching.py:126-153): raw device pointers of contiguous
 // x (B2,80,T), mask (B2,1,T), mu (B2,80,T), t (B2), spks (B2,80), cond (B2,80,T); result written into x.
+// ---- speed change between flow decoder and vocoder (cli/model.py:435-437) ------------------------------------------
+__global__ void mel_speed_k(const float* __restrict__ src, float* __restrict__ dst, int F_in, int F_out, float scale) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= F_out) return;
+    // aten area_pixel_compute_source_index (align_corners = false), in fp32 like aten's CPU / CUDA kernels
+    float x = scale * ((float)i + 0.5f) - 0.5f;
+    x = x < 0.f ? 0.f : x;
+    const int i0 = min((int)x, F_in - 1), i1 = i0 + (i0 < F_in - 1 ? 1 : 0);
+    const float l1 = x - (float)i0, l0 = 1.f - l1;
+    const float* r = src + (long)blockIdx.y * F_in;
+    dst[(long)blockIdx.y * F_out + i] = l0 * r[i0] + l1 * r[i1];
+}
+extern "C" int fy_mel_speed(const float* mel, int32_t rows, int32_t F_in, float* out, int32_t F_out, void* stream) {
+    FY_CHECK(mel && out && rows >= 1 && rows <= 65535 && F_in >= 1 && F_out >= 1, FY_ERR_ARG, "fy_mel_speed: bad arguments");
+    hipLaunchKernelGGL(mel_speed_k, dim3(cdiv(F_out, 256), rows), dim3(256), 0, (hipStream_t)stream, mel, out, F_in, F_out, (float)F_in / (float)F_out);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
 extern "C" int fy_dit_estimator(fy_flow* f, float* x, const float* mask, const float* mu, const float* t, const float* spks,
                                 const float* cond, int32_t T, int32_t B2, uint32_t flags, void* stream) {
     hipStream_t st = (hipStream_t)stream;

@@ -40,6 +40,7 @@ struct fy_llm {
     int *seq_ids;                                     // 0..max_batch-1
     int *counters = nullptr;                          // split-K arrival counters of the down projection
     int B = 0;
+    int step_next = 0, steps_cap = 0;      // fy_llm_begin / fy_llm_step: next decode step of the generation in progress, and its bound
     int n_speech() const { return cfg.speech_tokens + 200; }
     int qkv_dim() const { return (cfg.q_heads + 2 * cfg.kv_heads) * cfg.head_dim; }
     size_t cache_layer() const { return (size_t)max_batch * cfg.kv_heads * max_ctx * cfg.head_dim; }
@@ -561,11 +562,12 @@ static int llm_head_and_sample(fy_llm* l, int B, const float* rows, int32_t* out
     return FY_OK;
 }
 
-extern "C" int fy_llm_generate(fy_llm* l, const int32_t* text_ids, const int32_t* n_text_all, const int32_t* prompt_speech,
-                               const int32_t* n_prompt_speech, const int32_t* min_len, const int32_t* max_len, int32_t B,
-                               int32_t* out_ids, int32_t out_ld, int32_t* out_n, int32_t* raw_n, uint32_t flags, void* stream) {
+extern "C" int fy_llm_begin(fy_llm* l, const int32_t* text_ids, const int32_t* n_text_all, const int32_t* prompt_speech,
+                            const int32_t* n_prompt_speech, const int32_t* min_len, const int32_t* max_len, int32_t B,
+                            int32_t* out_ids, int32_t out_ld, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    FY_CHECK(l && text_ids && n_text_all && n_prompt_speech && min_len && max_len && out_ids && out_n, FY_ERR_ARG, "fy_llm_generate: null argument");
+    FY_CHECK(l && text_ids && n_text_all && n_prompt_speech && min_len && max_len && out_ids, FY_ERR_ARG, "fy_llm_generate: null argument");
+    l->step_next = l->steps_cap = 0;
     FY_CHECK(B >= 1 && B <= l->max_batch && out_ld >= 1, FY_ERR_ARG, "fy_llm_generate: batch %d outside [1, %d]", B, l->max_batch);
     const fy_llm_config& c = l->cfg;
     const int mb = l->max_batch, H = c.hidden;
@@ -615,24 +617,42 @@ extern "C" int fy_llm_generate(fy_llm* l, const int32_t* text_ids, const int32_t
     FY_TRY(llm_layers(l, R, l->row_seq, l->row_pos, false, st));
     hipLaunchKernelGGL(gather_rows_k, dim3(B), dim3(256), 0, st, l->h, l->last_row, l->hb, H);
     FY_TRY(llm_head_and_sample(l, B, l->hb, out_ids, out_ld, 0, st));
-    // decode: row b = sequence b at position st[pos][b]; everything a step needs is on the device
-    std::vector<int> done(mb);
-    for (int step = 1; step < steps; ++step) {
+    l->step_next = 1; l->steps_cap = steps;
+    return FY_OK;
+}
+
+// decode: row b = sequence b at position st[pos][b]; everything a step needs is on the device
+extern "C" int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t out_ld, int32_t* out_n, int32_t* raw_n,
+                           int32_t* finished, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(l && out_ids && out_n && out_ld >= 1 && n_steps >= 0, FY_ERR_ARG, "fy_llm_step: bad argument");
+    FY_CHECK(l->step_next >= 1, FY_ERR_STATE, "fy_llm_step: no generation in progress (call fy_llm_begin first)");
+    const int mb = l->max_batch, B = l->B;
+    const int end = (int)std::min<long>((long)l->step_next + n_steps, l->steps_cap);
+    std::vector<int> done(mb, 0);
+    auto read_done = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return FY_OK;
+    };
+    int step = l->step_next;
+    for (; step < end; ++step) {
         FY_TRY(llm_layers(l, B, l->seq_ids, l->st, true, st));
         FY_TRY(llm_head_and_sample(l, B, l->h, out_ids, out_ld, step, st));
         if ((step & 7) == 7) {
-            HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            FY_TRY(read_done());
             bool all = true;
             for (int b = 0; b < B; ++b) all = all && done[b];
-            if (all) break;
+            if (all) { ++step; break; }
         }
     }
+    l->step_next = step;
     HIP_TRY(hipMemcpyAsync(out_n, l->st + 2 * mb, B * sizeof(int), hipMemcpyDeviceToDevice, st));
     if (raw_n) HIP_TRY(hipMemcpyAsync(raw_n, l->st + 1 * mb, B * sizeof(int), hipMemcpyDeviceToDevice, st));
-    (void)flags;
+    FY_TRY(read_done());
+    if (finished)
+        for (int b = 0; b < B; ++b) finished[b] = (done[b] != 0 || l->step_next >= l->steps_cap) ? 1 : 0;
     if (l->sampler == 1) {                   // the reference raises RuntimeError from sampling_ids (llm.py:161-162)
-        HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
         std::vector<int> used(mb);
         HIP_TRY(hipMemcpyAsync(used.data(), l->st + 7 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -643,6 +663,16 @@ extern "C" int fy_llm_generate(fy_llm* l, const int32_t* text_ids, const int32_t
     }
     return FY_OK;
 }
+
+extern "C" int fy_llm_generate(fy_llm* l, const int32_t* text_ids, const int32_t* n_text_all, const int32_t* prompt_speech,
+                               const int32_t* n_prompt_speech, const int32_t* min_len, const int32_t* max_len, int32_t B,
+                               int32_t* out_ids, int32_t out_ld, int32_t* out_n, int32_t* raw_n, uint32_t flags, void* stream) {
+    (void)flags;
+    FY_CHECK(out_n, FY_ERR_ARG, "fy_llm_generate: null argument");
+    FY_TRY(fy_llm_begin(l, text_ids, n_text_all, prompt_speech, n_prompt_speech, min_len, max_len, B, out_ids, out_ld, stream));
+    return fy_llm_step(l, l->steps_cap, out_ids, out_ld, out_n, raw_n, nullptr, stream);
+}
+
 
 extern "C" int fy_llm_set_sampler(fy_llm* l, int32_t kind, const float* uniforms, int64_t n_uniforms, int32_t top_k, float top_p,
                                   int32_t win_size, float tau_r) {

@@ -94,6 +94,14 @@ class FlowEngine:
                                        flags, self._stream()))
         return mel
 
+    def speed(self, mel: torch.Tensor, speed: float) -> torch.Tensor:
+        """cli/model.py:435-437: F.interpolate(mel, size=int(F / speed), mode="linear") on (B, 80, F)."""
+        mel = mel.to(self.device, torch.float32).contiguous()
+        B, C, F = mel.shape
+        out = torch.empty(B, C, int(F / speed), device=self.device, dtype=torch.float32)
+        check(_lib.lib().fy_mel_speed(mel.data_ptr(), B * C, F, out.data_ptr(), out.shape[2], self._stream()))
+        return out
+
     def estimator(self, x, mask, mu, t, spks, cond, streaming: bool = False, flags: int = 0) -> torch.Tensor:
         """DiT.forward(x, mask, mu, t, spks, cond) on contiguous (B2, 80, T) tensors; returns the result (x is not modified)."""
         out = x.detach().clone().contiguous()

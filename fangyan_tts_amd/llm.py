@@ -74,11 +74,7 @@ class LlmEngine:
         except Exception:
             pass
 
-    def generate(self, text: Sequence[Sequence[int]], prompt_text: Sequence[Sequence[int]],
-                 prompt_speech: Sequence[Sequence[int]], min_len: Optional[Sequence[int]] = None,
-                 max_len: Optional[Sequence[int]] = None, min_ratio: float = 2, max_ratio: float = 20):
-        """Per-sequence python lists of ids -> (out_ids (B, max(max_len)) int32 CUDA, out_n (B) CUDA, raw_n (B) CUDA).
-        min/max default to llm.py:743-744 (2x / 20x the text-only length)."""
+    def _pack(self, text, prompt_text, prompt_speech, min_len, max_len, min_ratio, max_ratio):
         B = len(text)
         ids, n_all, ps, n_ps = [], [], [], []
         for b in range(B):
@@ -92,10 +88,34 @@ class LlmEngine:
         out = torch.zeros(B, out_ld, dtype=torch.int32, device=self.device)
         out_n = torch.zeros(B, dtype=torch.int32, device=self.device)
         raw_n = torch.zeros(B, dtype=torch.int32, device=self.device)
-        check(_lib.lib().fy_llm_generate(self._h, _lib.int_array(ids), _lib.int_array(n_all), _lib.int_array(ps or [0]),
-                                         _lib.int_array(n_ps), _lib.int_array(mn), _lib.int_array(mx), B, out.data_ptr(), out_ld,
-                                         out_n.data_ptr(), raw_n.data_ptr(), 0, self._stream()))
+        args = (_lib.int_array(ids), _lib.int_array(n_all), _lib.int_array(ps or [0]), _lib.int_array(n_ps), _lib.int_array(mn),
+                _lib.int_array(mx), B, out.data_ptr(), out_ld)
+        return args, out, out_n, raw_n
+
+    def generate(self, text: Sequence[Sequence[int]], prompt_text: Sequence[Sequence[int]],
+                 prompt_speech: Sequence[Sequence[int]], min_len: Optional[Sequence[int]] = None,
+                 max_len: Optional[Sequence[int]] = None, min_ratio: float = 2, max_ratio: float = 20):
+        """Per-sequence python lists of ids -> (out_ids (B, max(max_len)) int32 CUDA, out_n (B) CUDA, raw_n (B) CUDA).
+        min/max default to llm.py:743-744 (2x / 20x the text-only length)."""
+        args, out, out_n, raw_n = self._pack(text, prompt_text, prompt_speech, min_len, max_len, min_ratio, max_ratio)
+        check(_lib.lib().fy_llm_generate(self._h, *args, out_n.data_ptr(), raw_n.data_ptr(), 0, self._stream()))
         return out, out_n, raw_n
+
+    def begin(self, text, prompt_text, prompt_speech, min_len=None, max_len=None, min_ratio: float = 2, max_ratio: float = 20):
+        """The generator form of `inference` (llm.py:511-525 yields ids one by one): prefill + the first token.  Returns
+        (out_ids, out_n, raw_n) as `generate`; they fill up as `step` is called."""
+        args, out, out_n, raw_n = self._pack(text, prompt_text, prompt_speech, min_len, max_len, min_ratio, max_ratio)
+        check(_lib.lib().fy_llm_begin(self._h, *args, self._stream()))
+        self._gen = (out, out_n, raw_n, len(text))
+        return out, out_n, raw_n
+
+    def step(self, n_steps: int):
+        """Up to `n_steps` more tokens for the sequences still running -> (tokens kept so far per sequence, finished flags)."""
+        out, out_n, raw_n, B = self._gen
+        fin = (C.c_int32 * B)()
+        check(_lib.lib().fy_llm_step(self._h, int(n_steps), out.data_ptr(), out.shape[1], out_n.data_ptr(), raw_n.data_ptr(), fin,
+                                     self._stream()))
+        return out_n.cpu().tolist(), [bool(f) for f in fin]
 
     def set_sampler(self, kind: str = "greedy", uniforms: Optional[torch.Tensor] = None, top_k: int = 25, top_p: float = 0.8,
                     win_size: int = 10, tau_r: float = 0.1):

@@ -127,6 +127,11 @@ int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, const int32_
 int fy_dit_estimator(fy_flow* f, float* x, const float* mask, const float* mu, const float* t, const float* spks,
                      const float* cond, int32_t T, int32_t B2, uint32_t flags, void* stream);
 
+/* speed != 1 (cli/model.py:435-437): F.interpolate(mel, size=int(F / speed), mode="linear") between the flow decoder and
+ * the vocoder - torch's align_corners=False rule: out[i] blends the two frames around max(F_in / F_out * (i + 0.5) - 0.5, 0).
+ * mel (rows, F_in) -> out (rows, F_out), fp32 device, rows = B * 80.                                                       */
+int fy_mel_speed(const float* mel, int32_t rows, int32_t F_in, float* out, int32_t F_out, void* stream);
+
 /* ============================ speech-token language model ============================
  * replaces CosyVoice3LM.inference(...) + CosyVoiceModel.llm_job's token filter
  *   cosyvoice/llm/llm.py:713-748, 511-525; cosyvoice/cli/model.py:101-129                   */
@@ -155,6 +160,16 @@ void fy_llm_destroy(fy_llm* l);
 int fy_llm_generate(fy_llm* l, const int32_t* text_ids, const int32_t* n_text_all, const int32_t* prompt_speech,
                     const int32_t* n_prompt_speech, const int32_t* min_len, const int32_t* max_len, int32_t B,
                     int32_t* out_ids, int32_t out_ld, int32_t* out_n, int32_t* raw_n, uint32_t flags, void* stream);
+/* The same generation in pieces, for stream=True (cli/model.py:339-369 polls the token list its LM thread fills;
+ * CosyVoice3LM.inference is a generator, llm.py:511-525): fy_llm_begin = prefill + the first token; fy_llm_step = up to
+ * n_steps further tokens of the sequences that have not ended (same out_ids / out_ld as in fy_llm_begin; out_n / raw_n as
+ * above, counts so far); finished (nullable, host int32[B]) = 1 once a sequence met a stop token or its max_len.
+ * fy_llm_generate == fy_llm_begin + fy_llm_step(max over max_len): the ids are identical however the steps are cut.        */
+int fy_llm_begin(fy_llm* l, const int32_t* text_ids, const int32_t* n_text_all, const int32_t* prompt_speech,
+                 const int32_t* n_prompt_speech, const int32_t* min_len, const int32_t* max_len, int32_t B,
+                 int32_t* out_ids, int32_t out_ld, void* stream);
+int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t out_ld, int32_t* out_n, int32_t* raw_n,
+                int32_t* finished, void* stream);
 /* Sampler used by the following fy_llm_generate calls.  kind 0: the greedy rule above.  kind 1: the reference's default,
  * repetition-aware sampling (utils/common.py:137-166 `ras_sampling` with top_p, top_k, win_size, tau_r = 0.8, 25, 10, 0.1 in
  * cosyvoice3.yaml) inside the ignore_eos retry loop of `sampling_ids` (llm/llm.py:149-164; > 100 retries -> FY_ERR_STATE with

@@ -101,6 +101,9 @@ def test_automodel_drop_in_calls(model_dir):
     assert wav3.shape != wav.shape or maxerr(wav3, wav) > 1e-4                # the swapped weights are really in use
     with pytest.raises(RuntimeError):
         model.model.llm.load_state_dict(sd, strict=True)
+    # a text generator (inference_bistream) fails for CosyVoice3 in the reference with this AttributeError (llm.py:545)
+    with pytest.raises(AttributeError, match="llm_embedding"):
+        list(model.model.tts(text=(torch.zeros(1, 1, dtype=torch.int32) for _ in range(3)), flow_embedding=torch.zeros(1, 192)))
 
 
 def test_automodel_errors(tmp_path):

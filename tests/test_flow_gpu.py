@@ -131,3 +131,22 @@ def test_ragged_batch_equals_solo(tiny):
         solo = eng.inference(toks[b], [n], ptoks[b], [p], pfeats[b], [2 * p], emb[b:b + 1], z)
         e = maxerr(mel[b, :, : 2 * n], solo[0, :, : 2 * n])
         assert e < 1e-5, (b, e)
+
+
+@pytest.mark.parametrize("F,speed", [(150, 0.5), (150, 0.8), (150, 1.25), (1001, 1.7), (7, 2.0), (1, 0.5), (300, 3.0)])
+def test_mel_speed(tiny, F, speed):
+    """speed != 1 (cli/model.py:435-437): fy_mel_speed against torch's own F.interpolate(mode="linear") on the CPU, the
+    operation the reference calls.  fp32; the two differ at most by the rounding of the blend (fused or not): <= 2e-6 * max|mel|."""
+    eng, _, _ = tiny
+    mel = torch.from_numpy(synth.normal(f"in.speed.{F}", (2, 80, F))) * 3 - 5
+    want = torch.nn.functional.interpolate(mel, size=int(F / speed), mode="linear")
+    got = eng.speed(mel.to(DEV), speed).cpu()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-6 * float(mel.abs().max())
+
+
+def test_tts_speed(tiny):
+    """CosyVoice3Model.tts(speed=...) = the oracle pipeline with the same speed: sample count int(F / speed) * 480."""
+    eng, _, _ = tiny
+    mel = torch.from_numpy(synth.normal("in.speed.len", (1, 80, 41)))
+    assert eng.speed(mel.to(DEV), 1.3).shape[2] == int(41 / 1.3)

@@ -84,6 +84,43 @@ def test_forced_length_and_min_len(tiny):
     assert int(o[0, :40].max()) < cfg.speech_tokens and int(o[1, :33].max()) < cfg.speech_tokens
 
 
+def test_begin_step_equals_generate(tiny):
+    """The generator form (fy_llm_begin + fy_llm_step in uneven pieces, as stream=True drives it) emits the ids of one
+    fy_llm_generate call - against the reference's fixture, batched, greedy and repetition-aware sampling."""
+    from oracle.llm import silent_filter
+    cfg = tiny.cfg
+    cases = [(12, 8, 0), (16, 4, 10)]
+    texts, ptexts, ptoks = (list(x) for x in zip(*[llm_case(cfg, *c, "%d_%d_%d" % c) for c in cases]))
+    cap = [min(20 * len(t), 400) for t in texts]
+    for kind, fx in (("greedy", "llm_tiny.npz"), ("ras", "llm_ras_tiny.npz")):
+        if kind == "ras":
+            tiny.set_sampler("ras", _ras_rows(cases, tiny.max_batch))
+        try:
+            whole, whole_n, _ = tiny.generate(texts, ptexts, ptoks, max_len=cap)
+            whole, whole_n = whole.cpu().clone(), whole_n.cpu().tolist()
+            out, _, _ = tiny.begin(texts, ptexts, ptoks, max_len=cap)
+            n, fin = tiny.step(0)
+            assert not any(fin) and max(n) <= 1
+            pieces = [1, 7, 2, 13, 5, 64]
+            i = 0
+            while not all(fin):
+                n, fin = tiny.step(pieces[i % len(pieces)])
+                i += 1
+                assert i < 400
+            assert n == whole_n, (kind, n, whole_n)
+            out = out.cpu()
+            for b in range(len(cases)):
+                assert out[b, : n[b]].tolist() == whole[b, : n[b]].tolist(), (kind, b)
+            f = golden(fx)
+            c = cases[0]
+            ref = silent_filter(f["c%d_%d_%d.tokens" % c].tolist())
+            assert out[0, : n[0]].tolist() == ref
+            n2, fin2 = tiny.step(5)                          # stepping a finished generation is a no-op
+            assert n2 == n and all(fin2)
+        finally:
+            tiny.set_sampler("greedy")
+
+
 def _ras_rows(cases, n_rows):
     u = np.zeros((n_rows, 4096), dtype=np.float32)
     for b, c in enumerate(cases):

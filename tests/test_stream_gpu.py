@@ -102,8 +102,13 @@ def test_tts_stream_against_reference(tag, case):
     assert toks[0].cpu().tolist() == f[f"e2e.c{ctag}.tokens"].tolist()
     # every chunk against the oracle vocoder on the engine's own accumulated mel
     P = ohift.prepare({k: v.cpu().numpy() for k, v in sd[2].items()})
-    gen = m.tts(**inp, stream=True)
-    list(gen)
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    t_first = None
+    for _ in m.tts(**inp, stream=True):                      # second pass (warm): when does the first chunk leave?
+        t_first = t_first or time.perf_counter() - t0
+    note("parity_stream.json", f"tts_stream.{tag}.first_chunk_ms_of_total_ms", [round(1e3 * t_first, 1), round(1e3 * (time.perf_counter() - t0), 1)])
     mel_all = m.last_mel.cpu()
     first = f[f"e2e.c{ctag}.chunk_samples"].tolist()
     off, worst = 0, 0.0
