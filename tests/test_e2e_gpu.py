@@ -142,3 +142,40 @@ def test_pipeline_two_lm_handles(tiny):
         assert s == s2 and all(torch.equal(a, b) for a, b in zip(t, t2))
         for b in range(len(s)):
             assert maxerr(w[b, : s[b]], w2[b, : s2[b]]) < 1e-5
+
+
+def test_long_utterance_against_oracle():
+    """A 24 s utterance after a 10 s prompt (600 forced tokens, 250 prompt tokens: DiT sequence 1700 frames, 576 000
+    samples, 893 LM positions) at reduced width against the oracle pipeline: ids exact, mel and waveform within the
+    tolerances of the header.  Covers the sizes the short fixtures do not reach (multi-tile attention, long caches)."""
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    from oracle import flow as oflow, hift as ohift, llm as ollm
+    cfg = ModelCfg.tiny()
+    n, p = 600, 250
+    sd = [synth.state_dict_torch(m.manifest(), DEV, skip=("lm_head",)) for m in (cfg.llm, cfg.flow, cfg.hift)]
+    noise = torch.from_numpy(synth.flow_rand_noise(2 * (p + n)))
+    ri = torch.from_numpy(synth.hift_rand_ini())
+    sn = torch.from_numpy(synth.hift_sine_noise(2 * n * 480))
+    m = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, device=DEV, max_batch=1, max_text=64, max_prompt_tokens=p, max_tokens=n,
+                        rand_noise=noise, rand_ini=ri, sine_noise=sn)
+    inp, ctag = e2e_input(cfg, 30, 10, p, p)
+    wav, samples, toks = m.tts_batch([inp], min_len=[n], max_len=[n])
+    assert samples[0] == 2 * n * 480
+    PL = ollm.prepare({k: v.cpu().numpy() for k, v in sd[0].items()})
+    ref_ids = ollm.silent_filter(list(ollm.inference(inp["text"], inp["prompt_text"], inp["llm_prompt_speech_token"], PL, cfg.llm,
+                                                      min_len=n, max_len=n)))
+    got = toks[0].cpu().tolist()
+    first_bad = next((i for i, (g, r) in enumerate(zip(got, ref_ids)) if g != r), None)
+    assert got == ref_ids, (len(got), len(ref_ids), first_bad)
+    PF = oflow.prepare({k: v.cpu().numpy() for k, v in sd[1].items()})
+    mel_ref = oflow.inference(torch.tensor([got], dtype=torch.int32), inp["flow_prompt_speech_token"], inp["prompt_speech_feat"],
+                              inp["flow_embedding"], PF, cfg.flow, noise)
+    mel = m.last_mel.cpu()
+    e_mel = maxerr(mel, mel_ref)
+    note("parity_e2e.json", "long.mel_maxerr", e_mel)
+    assert e_mel < 8e-2
+    PH = ohift.prepare({k: v.cpu().numpy() for k, v in sd[2].items()})
+    ref, _ = ohift.inference(mel, PH, cfg.hift, ri, sn[:, : samples[0]])
+    e = maxerr(wav[:, : samples[0]], ref)
+    note("parity_e2e.json", "long.wav_vs_oracle_vocoder_on_engine_mel", e)
+    assert e < 1.5e-2
