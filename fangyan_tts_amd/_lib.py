@@ -99,6 +99,7 @@ def _declare(L):
     L.fy_llm_destroy.argtypes = [vp]
     L.fy_llm_destroy.restype = None
     L.fy_llm_generate.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, i32, vp, i32, vp, vp, u32, vp]
+    L.fy_stream_overlap.argtypes = [C.POINTER(C.c_void_p), i32, vp]
     L.fy_mel_speed.argtypes = [vp, i32, i32, vp, i32, vp]
     L.fy_llm_begin.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, i32, vp, i32, vp]
     L.fy_llm_step.argtypes = [vp, i32, vp, i32, vp, vp, i32p, vp]

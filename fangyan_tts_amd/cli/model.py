@@ -110,16 +110,15 @@ class CosyVoice3Model:
         n_prod = len(self.llms)
         if flow_cu_exclude is None:
             flow_cu_exclude = 80 if n_prod == 1 else 0
-        prio = [int(v) for v in os.environ.get("FY_PIPE_PRIO", "0,0").split(",")]      # stream priorities LM, flow: equal measured best (89.1 ms/step; LM high 89.9; flow high 125)
-        s_fv = self._masked_stream(flow_cu_exclude) if flow_cu_exclude > 0 else torch.cuda.Stream(device=dev, priority=prio[1])
+        pool = self._pipe_streams(1 + n_prod)
+        s_fv = self._masked_stream(flow_cu_exclude) if flow_cu_exclude > 0 else pool[0]
         qs = [queue.Queue(maxsize=2 * self.lm_group) for _ in range(n_prod)]
         z = torch.zeros(1, 0, dtype=torch.int32)
 
         def producer(pi):
             llm, q = self.llms[pi], qs[pi]
             try:
-                lm_stream = self._masked_stream(flow_cu_exclude, only=True, tag=pi) if (flow_cu_exclude > 0 and lm_isolate) else \
-                    torch.cuda.Stream(device=dev, priority=prio[0])
+                lm_stream = self._masked_stream(flow_cu_exclude, only=True, tag=pi) if (flow_cu_exclude > 0 and lm_isolate) else pool[1 + pi]
                 with torch.cuda.device(dev), torch.cuda.stream(lm_stream):
                     G = self.lm_group
                     for g0 in range(pi * G, len(batches), n_prod * G):
@@ -168,6 +167,50 @@ class CosyVoice3Model:
                     yield (wav if keep_on_device else wav.cpu()), samples, [out[b, : n_tok[b]] for b in range(len(inputs))]
             for t in threads:
                 t.join()
+
+    def _pipe_streams(self, n: int):
+        """The streams of the pipeline (flow + vocoder first, then one per LM handle), chosen once per model so that they are
+        served by different hardware pipes: two busy streams on one hardware queue or pipe take turns instead of overlapping
+        (15-60 % of the pipelined step on MI355X), and which queue a stream gets depends on the process's history, so the
+        pairs are measured (`fy_stream_overlap`, ~0.1 s) on a pool of 8 candidates."""
+        import ctypes
+        import itertools
+        import os
+        cache = self.__dict__.setdefault("_pipe_stream_sets", {})
+        if n in cache:
+            return cache[n]
+        pool = self.__dict__.setdefault("_pipe_stream_pool", [])
+        with torch.cuda.device(self.device):
+            while len(pool) < max(8, n):
+                st = torch.cuda.Stream(device=self.device)
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=self.device)          # first use binds the stream to its hardware queue
+                st.synchronize()
+                pool.append(st)
+            idx = [int(v) for v in os.environ.get("FY_STREAM_IDX", "").split(",") if v != ""]      # experiments: fixed choice
+            if len(idx) >= n:
+                cache[n] = [pool[i] for i in idx[:n]]
+                return cache[n]
+            m = len(pool)
+            ptrs = (ctypes.c_void_p * m)(*[s.cuda_stream for s in pool])
+            ratio = (ctypes.c_float * (m * m))()
+            from .. import _lib
+            _lib.check(_lib.lib().fy_stream_overlap(ptrs, m, ratio))
+        clash = lambda i, j: ratio[i * m + j] > 1.5
+        best = None
+        for c in itertools.combinations(range(m), n):          # fewest clashing pairs, first such subset in pool order
+            k = sum(clash(i, j) for i, j in itertools.combinations(c, 2))
+            if best is None or k < best[0]:
+                best = (k, c)
+            if k == 0:
+                break
+        self.pipe_stream_clashes = best[0]                       # 0 unless the device offers fewer independent queues than streams
+        cache[n] = [pool[i] for i in best[1]]
+        if os.environ.get("FY_PIPE_TRACE"):
+            import sys
+            print(f"[pipe] streams {best[1]} of {m}, {best[0]} clashing pairs; overlap ratios of stream 0: "
+                  f"{[round(ratio[j], 2) for j in range(m)]}", file=sys.stderr)
+        return cache[n]
 
     def _masked_stream(self, exclude: int, only: bool = False, tag: int = 0):
         """A HIP stream whose kernels may not run on the first `exclude` CUs of the mask - or, with only=True, may run on

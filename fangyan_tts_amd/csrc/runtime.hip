@@ -141,3 +141,57 @@ extern "C" int fy_prof_get(const char* name, double* total_ms, double* work, int
     }
     return FY_OK;
 }
+
+// ---- which streams can really run side by side? --------------------------------------------------------------------
+// A HIP stream is served by a hardware queue and the hardware queues by the four pipes of the compute micro-engine; a pipe
+// waits for a stream-ordered kernel to finish before it looks at the next packet, so two busy streams that land on one
+// queue - or on two queues of one pipe - take turns instead of overlapping (measured on MI355X: chains of 10 us kernels
+// from 2 threads take 1.0x the time of one chain on distinct pipes, 2.0x on a shared one; the pipelined benchmark loses
+// 15-60 % when two of its four streams collide).  Which queue a stream gets depends on how many streams the process has
+// created before, so it is measured: chains of short dependent kernels from two host threads, pair by pair.
+#include <chrono>
+#include <thread>
+#include <vector>
+__global__ void spin_k(float* y, int spin) {
+    float v = y[threadIdx.x];
+    for (int i = 0; i < spin; ++i) v = v * 1.0001f + 0.5f;
+    y[threadIdx.x] = v;
+}
+
+extern "C" int fy_stream_overlap(void* const* streams, int32_t n, float* ratio) {
+    FY_CHECK(streams && ratio && n >= 1 && n <= 32, FY_ERR_ARG, "fy_stream_overlap: bad arguments");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    float* buf = nullptr;
+    HIP_TRY(hipMalloc(&buf, (size_t)n * 64 * sizeof(float)));
+    (void)hipMemset(buf, 0, (size_t)n * 64 * sizeof(float));
+    const int reps = 200, spin = 600;                            // ~10 us per kernel, ~2.4 ms per chain
+    auto chain = [&](int i) {
+        (void)hipSetDevice(dev);
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(spin_k, dim3(1), dim3(64), 0, (hipStream_t)streams[i], buf + i * 64, spin);
+        (void)hipStreamSynchronize((hipStream_t)streams[i]);
+    };
+    auto timed = [&](int i, int j) {
+        auto t0 = std::chrono::steady_clock::now();
+        if (j < 0) chain(i);
+        else {
+            std::thread other(chain, j);
+            chain(i);
+            other.join();
+        }
+        return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    };
+    timed(0, -1);                                                // warm
+    double single = 1e30;
+    for (int r = 0; r < 3; ++r) single = std::min(single, timed(0, -1));
+    for (int i = 0; i < n; ++i) {
+        ratio[i * n + i] = 1.f;
+        for (int j = i + 1; j < n; ++j) {
+            const double t = std::min(timed(i, j), timed(i, j));
+            ratio[i * n + j] = ratio[j * n + i] = (float)(t / single);
+        }
+    }
+    (void)hipFree(buf);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}

@@ -40,6 +40,13 @@ void fy_prof_only(const char* name);   /* record only launches of this name (nul
 void fy_prof_reset(void);
 int fy_prof_get(const char* name, double* total_ms, double* work, int64_t* count);
 
+/* Which of `n` HIP streams can run side by side: ratio (host fp32, n x n) receives, per pair, the time two concurrent
+ * chains of short dependent kernels take over the time of one chain - ~1 when the two streams are served by different
+ * hardware pipes, ~2 when they share a hardware queue or a pipe (they then take turns).  Used by the host side to place
+ * the concurrent LM / flow streams of the pipelined path (cli/model.py runs the LM in its own thread beside
+ * token2wav, cli/model.py:101-129, 339-369); ~3 ms per pair.                                                           */
+int fy_stream_overlap(void* const* streams, int32_t n, float* ratio);
+
 /* ---- flags ------------------------------------------------------------------ */
 #define FY_PRECISE 1u /* split-bf16 (hi+lo) activations on the MFMA paths: fp32-class accuracy, 2x MFMA work */
 #define FY_DIRECT 2u  /* HiFT / DiT position conv: run convolutions on the exact fp32 VALU kernel */

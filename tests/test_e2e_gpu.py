@@ -179,3 +179,19 @@ def test_long_utterance_against_oracle():
     e = maxerr(wav[:, : samples[0]], ref)
     note("parity_e2e.json", "long.wav_vs_oracle_vocoder_on_engine_mel", e)
     assert e < 1.5e-2
+
+
+def test_stream_overlap_probe():
+    """fy_stream_overlap: symmetric, ~1 for streams that overlap and ~2 for a pair served by one hardware queue (a stream
+    against a second handle of itself must clash); tts_pipeline picks a clash-free set."""
+    import ctypes
+    from fangyan_tts_amd import _lib
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(3)]
+    ptrs = (ctypes.c_void_p * 4)(*([s.cuda_stream for s in streams] + [streams[0].cuda_stream]))
+    r = (ctypes.c_float * 16)()
+    _lib.check(_lib.lib().fy_stream_overlap(ptrs, 4, r))
+    r = np.array(r[:]).reshape(4, 4)
+    note("parity_e2e.json", "stream_overlap_ratios", [round(float(v), 2) for v in r.reshape(-1)])
+    assert np.allclose(r, r.T) and np.allclose(np.diag(r), 1.0)
+    assert r[0, 3] > 1.6                                   # the same stream twice: its two chains take turns
+    assert (r > 0.7).all() and (r < 4.0).all()
