@@ -187,10 +187,6 @@ class CosyVoice3Model:
                     torch.zeros(1, device=self.device)          # first use binds the stream to its hardware queue
                 st.synchronize()
                 pool.append(st)
-            idx = [int(v) for v in os.environ.get("FY_STREAM_IDX", "").split(",") if v != ""]      # experiments: fixed choice
-            if len(idx) >= n:
-                cache[n] = [pool[i] for i in idx[:n]]
-                return cache[n]
             m = len(pool)
             ptrs = (ctypes.c_void_p * m)(*[s.cuda_stream for s in pool])
             ratio = (ctypes.c_float * (m * m))()
