@@ -93,12 +93,13 @@ class CosyVoice3Model:
         flow decoder + vocoder of batch i (throughput-bound).  Yields (wav, n_samples, tokens) per batch, in
         order.  Same results as tts_batch.
 
-        flow_cu_exclude: CUs the flow / vocoder stream may NOT use (hipExtStreamCreateWithCUMask).  The LM's short
-        kernels otherwise queue behind GEMM workgroups that hold every CU's LDS; measured on MI355X at batch 8 the
-        stage time with ONE LM handle is 137 ms with no mask and 126 ms with 80 CUs kept clear; with TWO LM handles
-        it is 106 ms with no mask and the mask only hurts (175-200 ms).  None = 80 for one handle, 0 (no mask) otherwise.
+        flow_cu_exclude: CUs the flow / vocoder stream may NOT use (hipExtStreamCreateWithCUMask).  Measured on MI355X at
+        batch 8 with three LM handles and all streams on their own hardware pipes (`_pipe_streams`): 84.0 ms per step with no
+        mask, 84.1 / 84.2 with 16 / 32 CUs kept clear, 91.9 with 64 - the LM's short kernels are not waiting for CUs, they
+        are stretched by the memory traffic of the GEMMs beside them.  With ONE LM handle 80 clear CUs helped (137 -> 126 ms).
+        None = 80 for one handle, 0 (no mask) otherwise.
         lm_isolate additionally confines the LM streams to the excluded CUs (complementary masks); measured slower at every
-        split (32-96 CUs: 104-170 ms per step against 91 unmasked): the decode kernels want the whole chip for their short bursts.
+        split: the decode kernels want the whole chip for their short bursts.
         Set FY_PIPE_TRACE=1 for per-stage wall times on stderr."""
         import os
         import queue
@@ -110,8 +111,8 @@ class CosyVoice3Model:
         n_prod = len(self.llms)
         if flow_cu_exclude is None:
             flow_cu_exclude = 80 if n_prod == 1 else 0
-        pool = self._pipe_streams(1 + n_prod)
-        s_fv = self._masked_stream(flow_cu_exclude) if flow_cu_exclude > 0 else pool[0]
+        pool = self._pipe_streams(1 + n_prod, flow_cu_exclude)
+        s_fv = pool[0]
         qs = [queue.Queue(maxsize=2 * self.lm_group) for _ in range(n_prod)]
         z = torch.zeros(1, 0, dtype=torch.int32)
 
@@ -168,7 +169,7 @@ class CosyVoice3Model:
             for t in threads:
                 t.join()
 
-    def _pipe_streams(self, n: int):
+    def _pipe_streams(self, n: int, flow_exclude: int = 0):
         """The streams of the pipeline (flow + vocoder first, then one per LM handle), chosen once per model so that they are
         served by different hardware pipes: two busy streams on one hardware queue or pipe take turns instead of overlapping
         (15-60 % of the pipelined step on MI355X), and which queue a stream gets depends on the process's history, so the
@@ -177,8 +178,9 @@ class CosyVoice3Model:
         import itertools
         import os
         cache = self.__dict__.setdefault("_pipe_stream_sets", {})
-        if n in cache:
-            return cache[n]
+        key = (n, flow_exclude)
+        if key in cache:
+            return cache[key]
         pool = self.__dict__.setdefault("_pipe_stream_pool", [])
         with torch.cuda.device(self.device):
             while len(pool) < max(8, n):
@@ -187,6 +189,9 @@ class CosyVoice3Model:
                     torch.zeros(1, device=self.device)          # first use binds the stream to its hardware queue
                 st.synchronize()
                 pool.append(st)
+            # a CU-masked flow stream (flow_exclude > 0) is a stream of its own making: candidates for it go in front
+            masked = [self._masked_stream(flow_exclude, tag=100 + t) for t in range(4)] if flow_exclude > 0 else []
+            pool = masked + pool
             m = len(pool)
             ptrs = (ctypes.c_void_p * m)(*[s.cuda_stream for s in pool])
             ratio = (ctypes.c_float * (m * m))()
@@ -194,19 +199,21 @@ class CosyVoice3Model:
             _lib.check(_lib.lib().fy_stream_overlap(ptrs, m, ratio))
         clash = lambda i, j: ratio[i * m + j] > 1.5
         best = None
-        for c in itertools.combinations(range(m), n):          # fewest clashing pairs, first such subset in pool order
+        nm = len(masked)
+        cands = ((f,) + c for f in range(nm) for c in itertools.combinations(range(nm, m), n - 1)) if nm else itertools.combinations(range(m), n)
+        for c in cands:                                          # fewest clashing pairs, first such subset in pool order
             k = sum(clash(i, j) for i, j in itertools.combinations(c, 2))
             if best is None or k < best[0]:
                 best = (k, c)
             if k == 0:
                 break
         self.pipe_stream_clashes = best[0]                       # 0 unless the device offers fewer independent queues than streams
-        cache[n] = [pool[i] for i in best[1]]
+        cache[key] = [pool[i] for i in best[1]]
         if os.environ.get("FY_PIPE_TRACE"):
             import sys
             print(f"[pipe] streams {best[1]} of {m}, {best[0]} clashing pairs; overlap ratios of stream 0: "
                   f"{[round(ratio[j], 2) for j in range(m)]}", file=sys.stderr)
-        return cache[n]
+        return cache[key]
 
     def _masked_stream(self, exclude: int, only: bool = False, tag: int = 0):
         """A HIP stream whose kernels may not run on the first `exclude` CUs of the mask - or, with only=True, may run on
