@@ -122,6 +122,8 @@ def main():
     sn = torch.from_numpy(synth.hift_sine_noise(2 * N_TOK * 480)).to(dev)
     model = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=BATCH, max_text=64, max_prompt_tokens=P_TOK,
                             max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn, n_llm=1 if a.no_pipeline else a.llm_streams, lm_group=1 if a.no_pipeline else a.lm_group)
+    if not a.no_pipeline:
+        model.prepare_pipeline(a.flow_cu_exclude)        # stream placement on the hardware pipes: set-up, not part of a step
     log("engines ready")
     inputs = make_inputs(cfg, rank)
     forced = [N_TOK] * BATCH

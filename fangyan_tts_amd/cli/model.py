@@ -169,6 +169,13 @@ class CosyVoice3Model:
             for t in threads:
                 t.join()
 
+    def prepare_pipeline(self, flow_cu_exclude: Optional[int] = None):
+        """Place the pipeline's streams now (otherwise the first tts_pipeline call does it, ~0.1-0.4 s)."""
+        n_prod = len(self.llms)
+        if flow_cu_exclude is None:
+            flow_cu_exclude = 80 if n_prod == 1 else 0
+        self._pipe_streams(1 + n_prod, flow_cu_exclude)
+
     def _pipe_streams(self, n: int, flow_exclude: int = 0):
         """The streams of the pipeline (flow + vocoder first, then one per LM handle), chosen once per model so that they are
         served by different hardware pipes: two busy streams on one hardware queue or pipe take turns instead of overlapping
