@@ -166,8 +166,10 @@ class CosyVoice3:
     def inference_instruct(self, *a, **kw):
         raise AssertionError("inference_instruct is only implemented for CosyVoice!")           # cli/cosyvoice.py:118-119
 
-    def inference_vc(self, *a, **kw):
-        raise NotImplementedError("voice conversion is not part of this build")
+    def inference_vc(self, source_wav, prompt_wav, stream=False, speed=1.0):
+        """cli/cosyvoice.py:131-138: the source's speech tokens go straight to the flow decoder + vocoder (no LM)."""
+        model_input = self.frontend.frontend_vc(source_wav, prompt_wav, self.sample_rate)
+        yield from self._run(model_input, "<voice conversion>", stream, speed)
 
 
 def AutoModel(**kwargs):

@@ -269,7 +269,7 @@ class CosyVoice3Model:
     token_hop_len = 25                                          # cli/model.py:401: "must match training static_chunk_size"
 
     @torch.inference_mode()
-    def _tts_stream(self, d: Dict[str, torch.Tensor]):
+    def _tts_stream(self, d: Dict[str, torch.Tensor], source_tokens: Optional[torch.Tensor] = None):
         """The reference's chunk schedule: a chunk is cut whenever `hop + pre_lookahead` tokens beyond the offset exist (the
         first hop is padded so prompt + hop is a multiple of 25); every chunk re-runs the flow decoder over all tokens so far
         (chunk attention mask, finalize=False) and the vocoder over the whole mel so far (finalize=False), and yields the
@@ -290,9 +290,13 @@ class CosyVoice3Model:
         look, hop0 = self.cfg.flow.pre_lookahead, self.token_hop_len
         up = self.cfg.hift.upsample_total
         with self.lock:
-            self._arm_sampler()
-            out, _, _ = self.llm.begin(text, ptext, pspeech)
-            (n,), (done,) = self.llm.step(0)
+            if source_tokens is None:
+                self._arm_sampler()
+                out, _, _ = self.llm.begin(text, ptext, pspeech)
+                (n,), (done,) = self.llm.step(0)
+            else:                                               # vc_job (cli/model.py:131-133): the token list is given, complete
+                out = source_tokens.reshape(1, -1).to(self.device, torch.int32)
+                n, done = out.shape[1], True
             pad = -(-n_fp // hop0) * hop0 - n_fp
             offset, speech_offset, mel_all = 0, 0, None
 
@@ -326,8 +330,7 @@ class CosyVoice3Model:
             prompt_text=torch.zeros(1, 0, dtype=torch.int32), llm_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32),
             flow_prompt_speech_token=torch.zeros(1, 0, dtype=torch.int32), prompt_speech_feat=torch.zeros(1, 0, 80),
             source_speech_token=torch.zeros(1, 0, dtype=torch.int32), stream=False, speed=1.0, **kwargs):
-        if source_speech_token.shape[1] != 0:
-            raise NotImplementedError("voice conversion (inference_vc) is not part of this build")
+        vc = source_speech_token.shape[1] != 0                  # cli/model.py:334-337: vc_job instead of llm_job, no LM
         if not isinstance(text, torch.Tensor):
             # A text *generator* sends the reference to Qwen2LM.inference_bistream (cli/model.py:104-111), which reads
             # self.llm_embedding (llm/llm.py:545-546) - an attribute CosyVoice3LM.__init__ (llm.py:641-668) never creates, so
@@ -338,7 +341,15 @@ class CosyVoice3Model:
             assert speed == 1.0, "speed change only support non-stream inference mode"      # cli/model.py:436
             yield from self._tts_stream(dict(text=text, prompt_text=prompt_text, llm_prompt_speech_token=llm_prompt_speech_token,
                                              flow_prompt_speech_token=flow_prompt_speech_token,
-                                             prompt_speech_feat=prompt_speech_feat, flow_embedding=flow_embedding))
+                                             prompt_speech_feat=prompt_speech_feat, flow_embedding=flow_embedding),
+                                        source_tokens=source_speech_token if vc else None)
+            return
+        if vc:
+            inp = dict(flow_prompt_speech_token=flow_prompt_speech_token, prompt_speech_feat=prompt_speech_feat, flow_embedding=flow_embedding)
+            with self.lock:
+                out = source_speech_token.reshape(1, -1).to(self.device, torch.int32)
+                wav, samples = self._token2wav([inp], out, [out.shape[1]], speed)
+            yield {"tts_speech": wav.cpu()[:, : samples[0]]}
             return
         wav, samples, _ = self.tts_batch([dict(text=text, prompt_text=prompt_text, llm_prompt_speech_token=llm_prompt_speech_token,
                                                flow_prompt_speech_token=flow_prompt_speech_token,

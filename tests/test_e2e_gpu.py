@@ -195,3 +195,19 @@ def test_stream_overlap_probe():
     assert np.allclose(r, r.T) and np.allclose(np.diag(r), 1.0)
     assert r[0, 3] > 1.6                                   # the same stream twice: its two chains take turns
     assert (r > 0.7).all() and (r < 4.0).all()
+
+
+def test_voice_conversion_branch(tiny):
+    """tts(source_speech_token=...) (cli/model.py:334-337, vc_job): the given tokens go to the flow decoder + vocoder without
+    the LM - the same waveform as the text path that produced those tokens, whole and in streamed chunks."""
+    m, cfg, sd, ri, sn = tiny
+    inp, _ = e2e_input(cfg, 8, 6, 0, 12)
+    wav, samples, toks = m.tts_batch([inp])
+    vc_in = {k: inp[k] for k in ("flow_prompt_speech_token", "prompt_speech_feat", "flow_embedding")}
+    src = toks[0].cpu().reshape(1, -1)
+    out = list(m.tts(**vc_in, source_speech_token=src))
+    assert len(out) == 1 and torch.equal(out[0]["tts_speech"], wav[:, : samples[0]])
+    chunks = [o["tts_speech"] for o in m.tts(**vc_in, source_speech_token=src, stream=True)]
+    ref = [o["tts_speech"] for o in m.tts(**inp, stream=True)]
+    assert [c.shape for c in chunks] == [c.shape for c in ref]
+    assert all(maxerr(a, b) == 0.0 for a, b in zip(chunks, ref))
