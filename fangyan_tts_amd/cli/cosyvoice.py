@@ -145,6 +145,12 @@ class CosyVoice3:
             yield model_output
             start_time = time.time()
 
+    def inference_sft(self, tts_text, spk_id, stream=False, speed=1.0, text_frontend=True):
+        """cli/cosyvoice.py:80-89: a stored speaker embedding, no prompt audio (prompt lengths 0 on the flow side)."""
+        for i in self.frontend.text_normalize(tts_text, split=True, text_frontend=text_frontend):
+            model_input = self.frontend.frontend_sft(i, spk_id)
+            yield from self._run(model_input, i, stream, speed)
+
     def inference_zero_shot(self, tts_text, prompt_text, prompt_wav, zero_shot_spk_id="", stream=False, speed=1.0, text_frontend=True):
         if "<|endofprompt|>" not in prompt_text + tts_text:
             logging.warning("<|endofprompt|> not found in CosyVoice3 inference, check your input text")

@@ -53,6 +53,18 @@ class FakeFrontEnd:
                 "flow_prompt_speech_token": tok, "flow_prompt_speech_token_len": torch.tensor([p]), "prompt_speech_feat": feat,
                 "prompt_speech_feat_len": torch.tensor([2 * p]), "llm_embedding": emb, "flow_embedding": emb}
 
+    def frontend_sft(self, tts_text, spk_id):                               # cli/frontend.py:162-166
+        emb = torch.from_numpy(synth.normal("fe.spk." + spk_id, (1, 192)))
+        return {"text": self._ids(tts_text, 7), "text_len": torch.tensor([7]), "llm_embedding": emb, "flow_embedding": emb}
+
+    def frontend_vc(self, source_speech_16k, prompt_wav, resample_rate):    # cli/frontend.py:215-224
+        d = self.frontend_zero_shot("x", "y", prompt_wav, resample_rate, "")
+        src = torch.from_numpy(synth.randint("fe.src." + source_speech_16k, (1, 20), 0, 6561))
+        return {"source_speech_token": src, "source_speech_token_len": torch.tensor([20]),
+                "flow_prompt_speech_token": d["flow_prompt_speech_token"], "flow_prompt_speech_token_len": d["flow_prompt_speech_token_len"],
+                "prompt_speech_feat": d["prompt_speech_feat"], "prompt_speech_feat_len": d["prompt_speech_feat_len"],
+                "flow_embedding": d["flow_embedding"]}
+
     def frontend_instruct2(self, tts_text, instruct_text, prompt_wav, resample_rate, zero_shot_spk_id):
         d = self.frontend_zero_shot(tts_text, instruct_text, prompt_wav, resample_rate, zero_shot_spk_id)
         del d["llm_prompt_speech_token"], d["llm_prompt_speech_token_len"]
@@ -91,6 +103,13 @@ def test_automodel_drop_in_calls(model_dir):
     assert maxerr(w2[:, : s2[0]], wav) == 0.0
     z = list(model.inference_zero_shot("你好世界", "提示<|endofprompt|>", "prompt.wav"))[0]["tts_speech"]
     assert z.shape[1] % 480 == 0
+    # no prompt at all (inference_sft) and no LM at all (inference_vc: 20 source tokens -> 40 frames)
+    s = list(model.inference_sft("你好世界", "speaker0"))[0]["tts_speech"]
+    assert s.shape[1] % 480 == 0 and s.shape[1] > 0
+    v = list(model.inference_vc("source.wav", "prompt.wav"))[0]["tts_speech"]
+    assert v.shape == (1, 20 * 2 * 480)
+    vs = torch.cat([o["tts_speech"] for o in model.inference_vc("source.wav", "prompt.wav", stream=True)], dim=1)
+    assert vs.shape == v.shape
     # compare_inference.py:36-43: swap LLM weights, strict=False, extra keys ignored
     sd = {k: torch.from_numpy(v) for k, v in synth.state_dict(cfg.llm.manifest()).items() if "layers.1." in k}
     sd = {k: v * 0.5 for k, v in sd.items()}
