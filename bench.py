@@ -214,7 +214,7 @@ def main():
                 "measured_over": "HIP events on the launch stream around every launch of one step run alone after the timed region",
                 "inside_pipelined_steps": {"stream_interval_us_per_launch": round(1e3 * ms_t / max(n_t, 1), 2),
                                            "tflops_over_that_interval": round(flops_t / (ms_t * 1e-3) / 1e12, 2) if ms_t > 0 else None,
-                                           "note": "a repeat of the K timed steps; the interval includes waits for CUs held by the LM streams"},
+                                           "note": "a repeat of the K timed steps; beside the three LM streams the kernels run ~20 % longer and the stream spends longer between launches (DESIGN.md section 10)"},
                 "stage_ms_per_step_alone": {k: round(v[0], 3) for k, v in prof.items()}}
 
     out = {
