@@ -206,7 +206,7 @@ def main():
     traffic, pmc = None, os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
     if os.path.exists(pmc):
         traffic = json.load(open(pmc)).get("dit_mix_traffic_bytes_per_launch")
-    roofline = {"bound": "mfma", "kernel": "DiT linears: gemm256_k (LDS-DMA ring, 256x128x32 tiles, two workgroups per CU); gemm_bf16_k (128x128x64) for small grids", "achieved": round(achieved, 2),
+    roofline = {"bound": "mfma", "kernel": "DiT linears: gemm256_k (LDS-DMA ring, 256x128x32 tiles, two workgroups per CU); 128x128 ring tiles for small grids", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_gemm_pmc.json)",
                 "launches_per_step": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),

@@ -6,7 +6,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
 #define GM_BM 128
-int gemm_tile_override = 0;        // microbenchmarks: 0 auto; 128 / 64 register-staged kernel with that M tile; 2 / 256 ring kernel with 256x128 / 256x256 tiles
+int gemm_tile_override = 0;        // microbenchmarks: 0 auto; 128 / 64 register-staged kernel with that M tile; 2 / 3 / 256 ring kernel with 256x128 / 128x128 / 256x256 tiles
 #define GM_BN 128
 #define GM_BK 64
 #define GM_PITCH 72          // bf16 elements per LDS row: 64 + 8 pad (144 B: 16-B aligned, spreads ds_read_b128 over banks)
@@ -218,19 +218,21 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
 // BN = 256: 8 waves as 2 (M) x 4 (N), 128x64 per wave.  BN = 128: 4 x 2 waves of 64x64, <= 128 VGPRs and a 72 KB ring, so
 // two workgroups are resident per CU: one's prologue / epilogue bursts run under the other's K loop (the four DiT
 // products of a block: 184 -> 168 us), and the N = 1024 products get twice the tiles.
-template <int EPI, int BN>
+template <int EPI, int BN, int BM = 256>
 __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
     extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
     char* smem = reinterpret_cast<char*>(gm_smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    constexpr int WN = BN / 64, WM = 8 / WN, MI = 256 / WM / 32;          // waves along N / M, 32-row tiles per wave
-    constexpr int STAGE = (256 + BN) * G2_BK * 2, STAGES = (BN == 128 ? 3 : G2_RING_BYTES / STAGE), NB = BN / 128;   // NB: B DMAs per wave and stage
+    constexpr int NWAVE = BM == 128 ? 4 : 8;                             // BM 128 (with BN 128): 2 x 2 waves of 64x64, 48 KB ring, three workgroups per CU
+    constexpr int WN = BN / 64, WM = NWAVE / WN, MI = BM / WM / 32;       // waves along N / M, 32-row tiles per wave
+    constexpr int STAGE = (BM + BN) * G2_BK * 2, STAGES = (BN == 128 ? 3 : G2_RING_BYTES / STAGE), NB = BN / (NWAVE * 16);   // NB: B DMAs per wave and stage
+    constexpr int BOFF = BM * G2_BK * 2;                                  // the B tile follows the A tile inside a stage
     const int wm = wid / WN, wn = wid % WN, lr = lane & 31, kh = lane >> 5;
     // XCD-aware tile order (see gemm_bf16_k)
     const int ntn = N / BN, nwg = gridDim.x;
     const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    const int m0 = (wg / ntn) * 256, n0 = (wg % ntn) * BN;
+    const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
 
     // wave-instruction i (of 2) of wave wid fills stage bytes [(wid*2+i)*1024, +1024) of the A (and B) tile:
     // row = (wid*2+i)*16 + lane/4, slot = lane%4  ->  logical chunk = slot ^ ((row >> 2) & 3)
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
             __builtin_amdgcn_global_load_lds((const void*)(a_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + wid * 2048 + i * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(b_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + 16384 + wid * NB * 1024 + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(b_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + BOFF + wid * NB * 1024 + i * 1024), 16, 0, 0);
     };
 
     f32x16 acc[MI][2];
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
 #pragma unroll
     for (int i = 0; i < MI; ++i) { const int ra = wm * (MI * 32) + i * 32 + lr; a_off[i] = ra * 64; a_sw[i] = (ra >> 2) & 3; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int rb = wn * 64 + i * 32 + lr; b_off[i] = 16384 + rb * 64; b_sw[i] = (rb >> 2) & 3; }
+    for (int i = 0; i < 2; ++i) { const int rb = wn * 64 + i * 32 + lr; b_off[i] = BOFF + rb * 64; b_sw[i] = (rb >> 2) & 3; }
 
     const int nt = K / G2_BK;
 #pragma unroll
@@ -365,16 +367,16 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     }
 }
 
-template <int EPI, int BN>
+template <int EPI, int BN, int BM = 256>
 static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = BN == 128 ? (size_t)72 * 1024 : (size_t)G2_RING_BYTES;   // BN 128: two workgroups per CU
+    const size_t lds = BN == 128 ? (size_t)3 * (BM + BN) * G2_BK * 2 : (size_t)G2_RING_BYTES;   // BN 128: 72 KB (two workgroups per CU) or 48 KB (three)
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    dim3 grid((N / BN) * cdiv(M, 256));
-    hipLaunchKernelGGL((gemm256_k<EPI, BN>), grid, dim3(512), lds, st, A, lda, W, M, N, K, epi);
+    dim3 grid((N / BN) * cdiv(M, BM));
+    hipLaunchKernelGGL((gemm256_k<EPI, BN, BM>), grid, dim3(BM == 128 ? 256 : 512), lds, st, A, lda, W, M, N, K, epi);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -393,8 +395,8 @@ static int gemm_launch3(const void* A, int lda, const bf16_t* W, int M, int N, i
     return FY_OK;
 }
 
-// Which kernel: the LDS-DMA ring with 256x128 tiles whenever its tiles cover most of the chip, the register-staged
-// 128x128x64 kernel for small grids and for the split operand of the precise form.
+// Which kernel: the LDS-DMA ring - 256x128 tiles when they cover most of the chip, 128x128 tiles for smaller grids; the
+// register-staged 128x128x64 kernel for N % 128 != 0 and for the split operand of the precise form.
 template <bool PRECISE, int EPI>
 static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     if (gemm_tile_override == 64) return gemm_launch3<PRECISE, EPI, 64>(A, lda, W, M, N, K, epi, st);
@@ -414,7 +416,10 @@ static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, i
         }
         if (gemm_tile_override == 256 && N % 256 == 0) return gemm_launch_256<EPI, 256>((const bf16_t*)A, lda, W, M, N, K, epi, st);
         const int t128 = (N / 128) * cdiv(M, 256);
-        if (gemm_tile_override == 2 || 5 * t128 >= 3 * cus) return gemm_launch_256<EPI, 128>((const bf16_t*)A, lda, W, M, N, K, epi, st);
+        if (gemm_tile_override == 2 || (gemm_tile_override == 0 && 5 * t128 >= 3 * cus)) return gemm_launch_256<EPI, 128>((const bf16_t*)A, lda, W, M, N, K, epi, st);
+        // fewer tiles than that: the same ring with 128x128 tiles (4 waves, 48 KB, three workgroups per CU) - at M = 3200
+        // 18 / 29 / 36 us for the out / ff2 / qkv shapes against 21 / 34 / 41 with the register-staged kernel
+        return gemm_launch_256<EPI, 128, 128>((const bf16_t*)A, lda, W, M, N, K, epi, st);
     }
     return gemm_launch3<PRECISE, EPI, 128>(A, lda, W, M, N, K, epi, st);
 }

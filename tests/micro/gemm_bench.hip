@@ -37,8 +37,8 @@ int main(int argc, char** argv) {
         {12800, 1024, 1024, 0, "M=12800 bf16 out"}, {12800, 3072, 1024, 0, "M=12800 qkv"}, {12800, 2048, 1024, 0, "M=12800 ff1"}, {3200, 3072, 1024, 0, "M=3200 qkv"}, {3200, 1024, 1024, 1, "M=3200 out"}, {3200, 1024, 2048, 1, "M=3200 ff2"}, {6400, 1024, 320, 2, "in-proj f32 out"}};
     extern int gemm_tile_override;
     if (pmc) g_warm = 1;
-    for (int tile : {128, 0, 2, 256}) {
-        if (pmc && tile) continue; gemm_tile_override = tile; printf("--- tile override %d (128: register-staged 128x128x64 only; 0: automatic choice; 2: LDS-DMA ring with 256x128 tiles wherever it applies)\n", tile);
+    for (int tile : {128, 0, 2, 3}) {
+        if (pmc && tile) continue; gemm_tile_override = tile; printf("--- tile override %d (128: register-staged 128x128x64 only; 0: automatic choice; 2 / 3: LDS-DMA ring with 256x128 / 128x128 tiles wherever it applies)\n", tile);
     for (auto& s : shapes) {
         GemmEpi e;
         e.bias = bias;
