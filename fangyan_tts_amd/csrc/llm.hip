@@ -41,6 +41,7 @@ struct fy_llm {
     int *counters = nullptr;                          // split-K arrival counters of the down projection
     int B = 0;
     int step_next = 0, steps_cap = 0;      // fy_llm_begin / fy_llm_step: next decode step of the generation in progress, and its bound
+    bool all_done = false;                 // every sequence of that generation has ended: further steps are no-ops
     int n_speech() const { return cfg.speech_tokens + 200; }
     int qkv_dim() const { return (cfg.q_heads + 2 * cfg.kv_heads) * cfg.head_dim; }
     size_t cache_layer() const { return (size_t)max_batch * cfg.kv_heads * max_ctx * cfg.head_dim; }
@@ -568,6 +569,7 @@ extern "C" int fy_llm_begin(fy_llm* l, const int32_t* text_ids, const int32_t* n
     hipStream_t st = (hipStream_t)stream;
     FY_CHECK(l && text_ids && n_text_all && n_prompt_speech && min_len && max_len && out_ids, FY_ERR_ARG, "fy_llm_generate: null argument");
     l->step_next = l->steps_cap = 0;
+    l->all_done = false;
     FY_CHECK(B >= 1 && B <= l->max_batch && out_ld >= 1, FY_ERR_ARG, "fy_llm_generate: batch %d outside [1, %d]", B, l->max_batch);
     const fy_llm_config& c = l->cfg;
     const int mb = l->max_batch, H = c.hidden;
@@ -628,7 +630,7 @@ extern "C" int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t
     FY_CHECK(l && out_ids && out_n && out_ld >= 1 && n_steps >= 0, FY_ERR_ARG, "fy_llm_step: bad argument");
     FY_CHECK(l->step_next >= 1, FY_ERR_STATE, "fy_llm_step: no generation in progress (call fy_llm_begin first)");
     const int mb = l->max_batch, B = l->B;
-    const int end = (int)std::min<long>((long)l->step_next + n_steps, l->steps_cap);
+    const int end = l->all_done ? l->step_next : (int)std::min<long>((long)l->step_next + n_steps, l->steps_cap);
     std::vector<int> done(mb, 0);
     auto read_done = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -650,6 +652,11 @@ extern "C" int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t
     HIP_TRY(hipMemcpyAsync(out_n, l->st + 2 * mb, B * sizeof(int), hipMemcpyDeviceToDevice, st));
     if (raw_n) HIP_TRY(hipMemcpyAsync(raw_n, l->st + 1 * mb, B * sizeof(int), hipMemcpyDeviceToDevice, st));
     FY_TRY(read_done());
+    {
+        bool all = true;
+        for (int b = 0; b < B; ++b) all = all && done[b];
+        l->all_done = all;
+    }
     if (finished)
         for (int b = 0; b < B; ++b) finished[b] = (done[b] != 0 || l->step_next >= l->steps_cap) ? 1 : 0;
     if (l->sampler == 1) {                   // the reference raises RuntimeError from sampling_ids (llm.py:161-162)
