@@ -31,6 +31,7 @@ N_TOK = 75            # forced speech tokens per utterance (3 s)
 P_TOK = 125           # prompt speech tokens (5 s)
 BATCH = 8
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+PEAK_HBM_GBPS = 8000.0        # HBM3E, same guide (measured float4 copy: 6290 GB/s)
 
 
 def make_inputs(cfg, rank):
@@ -217,6 +218,36 @@ def main():
                                            "note": "a repeat of the K timed steps; beside the three LM streams the kernels run ~20 % longer and the stream spends longer between launches (DESIGN.md section 10)"},
                 "stage_ms_per_step_alone": {k: round(v[0], 3) for k, v in prof.items()}}
 
+    # The kernels that hold the GPU longest are the LM's decode products (gemv_lds_k / gemv_direct_k: 97 of the 122 launches of
+    # a token step, ~60 % of all kernel time by rocprofv3): HBM-bound by SURVEY 8(d) - the bf16 weights are streamed once per
+    # token step for the 8 rows.  Kernel level: algorithmic bytes (the weights of each product) over the HIP-event duration of
+    # every launch of the step run alone; step level: 727.8 MB over the un-instrumented time of a token step.
+    ms_v, bytes_v, n_v = prof["gemv"]
+    text = [d["text"].reshape(-1).tolist() for d in inputs]
+    ptext = [d["prompt_text"].reshape(-1).tolist() for d in inputs]
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    model.llms[0].generate(text, ptext, [[] for _ in inputs], min_len=forced, max_len=forced)
+    torch.cuda.synchronize()
+    lm_ms = 1e3 * (time.perf_counter() - t2)
+    gv_traffic, gv_pmc = None, os.path.join(ROOT, "profiles", "r01_gemv_pmc.json")
+    if os.path.exists(gv_pmc):
+        sh = json.load(open(gv_pmc))["shapes"]
+        per_layer = sum(sh[k]["fetched_bytes"] for k in ("qkv+norm", "o_proj", "gate/up+norm", "down (split-K 4)"))
+        gv_traffic = int((cfg.llm.layers * per_layer + sh["head+norm"]["fetched_bytes"]) / (4 * cfg.llm.layers + 1))
+    gbps = bytes_v / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0
+    step_bytes = 727810048
+    roofline_lm = {"bound": "hbm", "kernel": "LM decode products: gemv_lds_k / gemv_direct_k (qkv, o-proj, gate/up, down of 24 layers + llm_decoder; 97 launches per token step)",
+                   "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                   "traffic": gv_traffic, "traffic_unit": "bytes per launch, mean over a token step (rocprofv3 PMC on the stand-alone driver, profiles/r01_gemv_pmc.json)",
+                   "launches_per_step": n_v, "avg_launch_us": round(1e3 * ms_v / max(n_v, 1), 2),
+                   "algorithmic_bytes_per_launch": int(bytes_v / max(n_v, 1)),
+                   "measured_over": "HIP events on the launch stream around every launch of one step run alone; the two event records add ~2 us to a ~10 us "
+                                    "launch (rocprofv3 over bench.py --no-pipeline: 10.1 us, profiles/r01_bench_nopipeline_kernel_stats.csv)",
+                   "decode_step_level": {"weight_bytes_per_token_step": step_bytes, "ms_per_token_step": round(lm_ms / N_TOK, 4),
+                                         "GBps": round(step_bytes / (lm_ms / N_TOK * 1e-3) / 1e9, 1),
+                                         "note": "un-instrumented LM call alone (prefill of ~25 rows per sequence included); bound by 122 dependent launches per token, not by bandwidth"}}
+
     out = {
         "metric": "synthesised audio sec/sec (RTF^-1) CosyVoice3-0.5B instruct, batch 8",
         "value": round(value, 3), "unit": "audio_s/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -227,7 +258,8 @@ def main():
                    "batch_per_gpu": BATCH, "tokens_per_utt": N_TOK, "prompt_tokens": P_TOK, "parallelism": f"dp{world}",
                    "steps_pipelined": not a.no_pipeline, "llm_streams": 1 if a.no_pipeline else a.llm_streams, "lm_group": 1 if a.no_pipeline else a.lm_group, "flow_cu_exclude": a.flow_cu_exclude, "batch_latency_ms_unpipelined": round(latency_ms, 1),
                    "weights": "random-init, CosyVoice3-0.5B shapes (859 M params)"},
-        "roofline": roofline,
+        "roofline": roofline_lm,
+        "roofline_dit_linears": roofline,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("timing the CPU oracle on one utterance")

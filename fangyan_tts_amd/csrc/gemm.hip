@@ -739,7 +739,7 @@ int gemv_bf16w(const GemvArgs& a, hipStream_t st) {
     FY_CHECK((a.mode != GV_SWIGLU && a.mode != GV_SWIGLU_SPLIT) || a.N % 2 == 0, FY_ERR_ARG, "gemv: SwiGLU rows must come in interleaved pairs");
     FY_CHECK(((uintptr_t)a.W & 15) == 0, FY_ERR_ARG, "gemv: weights must be 16-B aligned");
     dim3 grid(cdiv(a.N, 32), 1, cdiv(a.R, 8));
-    ProfScope prof("gemv", 2.0 * a.N * a.K, st);
+    ProfScope prof("gemv", 2.0 * a.N * a.K, st);                 // work = the product's bf16 weight bytes (= flops per row)
     if (a.x_split) {
         FY_CHECK(!a.norm_w && a.ldx % 8 == 0 && ((uintptr_t)a.x_split & 15) == 0, FY_ERR_ARG, "gemv: bad pre-split operand");
         int KS = (a.K >= 2048 && a.partial && a.counters) ? 4 : 1;
