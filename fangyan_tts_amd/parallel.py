@@ -20,26 +20,28 @@ def shard_range(n_items: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < extra else 0))
 
 
-def gather_audio(wav: torch.Tensor, n_samples: Sequence[int], group=None) -> Tuple[torch.Tensor, List[List[int]]]:
+def gather_audio(wav: torch.Tensor, n_samples: Sequence[int], group=None, b_cap: int = 64) -> Tuple[torch.Tensor, List[List[int]]]:
     """wav (b, S) of this rank's utterances, n_samples their valid lengths ->
     (all wavs (world * b_max, S_max) in rank order, per-rank length lists) on every rank.
-    Two collectives: one tiny all-gather of (b, S, lengths), one fused all-gather of the padded audio."""
+    Two collectives: one tiny all-gather of (b, S, lengths) in a fixed-size record (b <= b_cap), one fused all-gather of the
+    padded audio."""
     world = dist.get_world_size(group)
     dev = wav.device
     b, S = wav.shape
-    head = torch.tensor([b, S], dtype=torch.int64, device=dev)
-    heads = [torch.zeros_like(head) for _ in range(world)]
-    dist.all_gather(heads, head, group=group)
-    b_max, s_max = int(max(h[0] for h in heads)), int(max(h[1] for h in heads))
-    lens = torch.zeros(b_max, dtype=torch.int64, device=dev)
-    lens[:b] = torch.as_tensor(list(n_samples), dtype=torch.int64)
-    all_lens = torch.zeros(world * b_max, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_lens, lens, group=group)
+    assert b <= b_cap and len(n_samples) == b, "more utterances per rank than the header record holds"
+    rec = 2 + b_cap
+    head = torch.zeros(rec, dtype=torch.int64)
+    head[0], head[1] = b, S
+    head[2: 2 + b] = torch.as_tensor(list(n_samples), dtype=torch.int64)
+    heads = torch.zeros(world * rec, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(heads, head.to(dev), group=group)
+    heads = heads.cpu().reshape(world, rec)
+    b_max, s_max = int(heads[:, 0].max()), int(heads[:, 1].max())
     if (b, S) != (b_max, s_max):
         pad = torch.zeros(b_max, s_max, dtype=wav.dtype, device=dev)
         pad[:b, :S] = wav
         wav = pad
     out = torch.empty(world * b_max, s_max, dtype=wav.dtype, device=dev)
     dist.all_gather_into_tensor(out, wav.contiguous(), group=group)
-    per_rank = [[int(v) for v in all_lens[r * b_max: r * b_max + int(heads[r][0])].tolist()] for r in range(world)]
+    per_rank = [heads[r, 2: 2 + int(heads[r, 0])].tolist() for r in range(world)]
     return out, per_rank
