@@ -6,8 +6,11 @@
 
 A step = one pass of the hot path (speech-token LM greedy decode -> 10-step CFG flow matching over
 the DiT -> HiFT vocoder) over one batch of 8 synthetic instruct utterances per GPU, inputs resident
-in HBM, outputs (wavs) resident in HBM; with N > 1 every rank runs its own 8 utterances
-(data-parallel, no data-path collective) and one RCCL all-gather collects the finished audio.
+in HBM, outputs (wavs) copied to host memory inside the timed region; with N > 1 every
+rank runs its own 8 utterances (data-parallel, no data-path collective), one RCCL all-gather collects
+the finished audio and every rank copies it to the host.  `--gpus N` without an outer launcher starts
+its own N ranks (one child `torch.distributed.run`).  After the timed region utterance 0 of the last
+timed step is checked against the CPU oracle ("checked" in the JSON line).
 
 Workload (cfg 2 = BASELINE.json configs[1]): instruct text 8 ids + tts text U{10..20} ids,
 5 s prompt (125 speech tokens / 250 mel frames, x-vector 192), forced length n = 75 tokens per
@@ -54,8 +57,9 @@ def make_inputs(cfg, rank):
     return inputs
 
 
-def cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inp, noise, ri, sn):
-    """The oracle (CPU restatement, kind 'port') on ONE utterance of the same workload."""
+def cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inp, noise, ri, sn, timed=None):
+    """The oracle (CPU restatement, kind 'port') on ONE utterance of the same workload; with `timed` (the outputs of the
+    last timed step) utterance 0 of the timed run is checked against it."""
     from oracle import flow as oflow, hift as ohift, llm as ollm, pipeline as opipe
     # the GPU box gives one job a 16-core share whatever os.cpu_count() says
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
@@ -67,9 +71,70 @@ def cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inp, noise, ri, sn):
     out = opipe.tts(inp, PL, PF, PH, cfg, noise.cpu(), ri.cpu(), sn.cpu(), min_len=N_TOK, max_len=N_TOK)
     dt = time.time() - t0
     audio = out["tts_speech"].shape[1] / 24000.0
-    return {"value": round(audio / dt, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
+    base = {"value": round(audio / dt, 4), "unit": "audio_s/s", "cores": cores, "kind": "port",
             "sample": f"1 utterance of the same workload (5 s prompt, {N_TOK} forced tokens -> {audio:.1f} s audio) in {dt:.1f} s, "
                       f"torch fp32 on {cores} threads"}
+    checked = None
+    if timed is not None:
+        # utterance 0 of the LAST TIMED step against the oracle: ids exact; mel within 3x the error measured for the bf16
+        # flow decoder at this size (1.3e-2, gpurun_out/parity_flow.json); wav against the oracle vocoder run on the engine's
+        # own mel (sample-wise comparison with an fp32-mel waveform is only meaningful for the first frames: the harmonic
+        # source integrates f0, tests/test_e2e_gpu.py) within 3x the measured 8e-4, and the log-mel distance between the two
+        # complete waveforms (phase-insensitive) for the whole utterance
+        ids = timed["toks"][0].reshape(-1).tolist()
+        ref_ids = out["tokens"].reshape(-1).tolist()
+        n = len(ref_ids)
+        mel = timed["mel"][0:1, :, : 2 * n].float().cpu()
+        e_mel = float((mel - out["mel"]).abs().max()) if mel.shape == out["mel"].shape else float("inf")
+        S = out["tts_speech"].shape[1]
+        wav = timed["wav"][0:1, :S]
+        ref_wav, _ = ohift.inference(mel, PH, cfg.hift, ri.cpu(), sn.cpu()[:, :S])
+        e_wav = float((wav - ref_wav).abs().max())
+        e_lm = logmel_distance(wav, out["tts_speech"])
+        checked = {"what": "utterance 0 of the last timed step vs the CPU oracle", "ids_equal": ids == ref_ids, "n_ids": n,
+                   "mel_max_abs_err": round(e_mel, 5), "mel_tol": 4e-2,
+                   "wav_vs_oracle_vocoder_on_engine_mel": round(e_wav, 6), "wav_tol": 2.5e-3,
+                   "logmel_db_vs_oracle_wav": round(e_lm, 3), "logmel_db_tol": 1.0,
+                   "ok": bool(ids == ref_ids and e_mel <= 4e-2 and e_wav <= 2.5e-3 and e_lm <= 1.0)}
+    return base, checked
+
+
+def logmel_distance(a, b, n_fft=1024, hop=256, n_mels=80, sr=24000):
+    """Mean absolute difference, in dB, of the log-mel spectra of two waveforms: a phase-insensitive comparison (the
+    harmonic source's phase is an integral of f0, so two correct waveforms from slightly different mels drift apart
+    sample-wise while sounding the same)."""
+    import math
+    n = min(a.shape[-1], b.shape[-1])
+    win = torch.hann_window(n_fft)
+    fb = torch.zeros(n_mels, n_fft // 2 + 1)
+    mel = lambda f: 2595.0 * math.log10(1.0 + f / 700.0)
+    pts = torch.linspace(mel(0.0), mel(sr / 2), n_mels + 2)
+    hz = 700.0 * (10.0 ** (pts / 2595.0) - 1.0)
+    bins = torch.arange(n_fft // 2 + 1) * sr / n_fft
+    for m in range(n_mels):
+        lo, c, hi = hz[m], hz[m + 1], hz[m + 2]
+        fb[m] = torch.clamp(torch.minimum((bins - lo) / (c - lo), (hi - bins) / (hi - c)), min=0.0)
+    def lm(x):
+        sp = torch.stft(x.reshape(-1)[:n].float(), n_fft, hop, window=win, return_complex=True).abs() ** 2
+        return 10.0 * torch.log10(fb @ sp + 1e-7)
+    return float((lm(a) - lm(b)).abs().mean())
+
+
+def spawn_ranks(n):
+    import socket
+    import subprocess
+    from fangyan_tts_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):                  # one builder, before the ranks exist (they require it prebuilt)
+        build.build(verbose=False)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def log(msg):
@@ -88,6 +153,12 @@ def main():
     ap.add_argument("--lm-group", type=int, default=1, help="consecutive steps whose LM decode runs as one call")
     ap.add_argument("--flow-cu-exclude", type=int, default=None, help="CUs kept clear of the flow / vocoder stream")
     a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no outer launcher: start one rank per GPU ourselves (the reference's own multi-GPU inference pattern,
+        # CosyVoice/runtime/triton_trtllm/offline_inference.py:312-322).  A child process, started before this one has
+        # touched the GPU; its stdout (rank 0's JSON line) and exit code are relayed.
+        sys.exit(spawn_ranks(a.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -111,6 +182,8 @@ def main():
     from fangyan_tts_amd.cli.model import CosyVoice3Model
     from fangyan_tts_amd.spec import ModelCfg
     if not os.path.exists(_lib.LIB_PATH):
+        if world > 1:
+            raise RuntimeError("libfy_cosy3.so is missing: build it once before starting the ranks (python -m fangyan_tts_amd.build)")
         build.build(verbose=False)
     cfg = ModelCfg()
     log("generating synthetic weights on the GPU")
@@ -130,22 +203,28 @@ def main():
     forced = [N_TOK] * BATCH
     from fangyan_tts_amd.parallel import gather_audio
 
-    def step():
-        wav, samples, _ = model.tts_batch(inputs, min_len=forced, max_len=forced, keep_on_device=True)
+    S_MAX = N_TOK * 2 * cfg.hift.upsample_total
+    last = {}
+
+    def deliver(wav, samples, toks):
+        """The metric's end point: all wavs resident on the host - after the all-gather for N > 1."""
         if world > 1:
-            gather_audio(wav.cpu() if rehearsal else wav, samples)    # RCCL over xGMI: every rank's finished audio, on every rank
+            wav, _ = gather_audio(wav.cpu() if rehearsal else wav, samples, b_max=BATCH, s_max=S_MAX)
+        last["wav"], last["toks"], last["mel"] = wav.cpu(), toks, model.last_mel       # D2H inside the timed region
         return samples
 
+    def step():
+        return deliver(*model.tts_batch(inputs, min_len=forced, max_len=forced, keep_on_device=True))
+
     def run(k):
-        """k steps.  Consecutive steps are software-pipelined over two HIP streams (the LM of step i+1 beside the
+        """k steps.  Consecutive steps are software-pipelined over HIP streams (the LM of the next steps beside the
         flow decoder + vocoder of step i); every step still runs the whole path on its own batch."""
         if a.no_pipeline:
             return [step() for _ in range(k)][-1]
         samples = None
-        for wav, samples, _ in model.tts_pipeline([inputs] * k, min_len=[forced] * k, max_len=[forced] * k, keep_on_device=True,
-                                                  flow_cu_exclude=a.flow_cu_exclude, lm_isolate=a.lm_isolate):
-            if world > 1:
-                gather_audio(wav.cpu() if rehearsal else wav, samples)
+        for out in model.tts_pipeline([inputs] * k, min_len=[forced] * k, max_len=[forced] * k, keep_on_device=True,
+                                      flow_cu_exclude=a.flow_cu_exclude, lm_isolate=a.lm_isolate):
+            samples = deliver(*out)
         return samples
 
     if a.warmup:
@@ -162,6 +241,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    timed = {k: (v.clone() if torch.is_tensor(v) else [t.cpu() for t in v]) for k, v in last.items()}      # the last timed step's outputs
     # roofline: the same K pipelined steps once more with HIP events around every launch of the dominant kernels (the DiT
     # linears) on the stream they are launched on.  Not in the timed pass itself: the 1800 event records per step cost
     # the flow stream ~6 % (88.5 against 83 ms per step); only that name is recorded, so the LM threads pay nothing.
@@ -263,7 +343,7 @@ def main():
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("timing the CPU oracle on one utterance")
-        out["cpu_baseline"] = cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inputs[0], noise, ri, sn)
+        out["cpu_baseline"], out["checked"] = cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inputs[0], noise, ri, sn, timed)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

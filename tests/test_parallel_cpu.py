@@ -38,9 +38,18 @@ def _worker(rank, world, port, ret):
     wav = torch.zeros(len(mine), S)
     for j, i in enumerate(mine):
         wav[j, : lens[j]] = torch.arange(lens[j], dtype=torch.float32) + 10000.0 * i
-    out, per_rank = gather_audio(wav, lens)
     ok = True
     b_max = max(len(shard_range(n_utts, r, world)) for r in range(world))
+    for fixed in (False, True):                       # header + audio in two collectives, or one fixed-size record
+        out, per_rank = gather_audio(wav, lens, b_max=b_max, s_max=1400) if fixed else gather_audio(wav, lens)
+        ok &= _check(out, per_rank, n_utts, world, b_max)
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check(out, per_rank, n_utts, world, b_max):
+    ok = True
     for r in range(world):
         for j, i in enumerate(shard_range(n_utts, r, world)):
             n = per_rank[r][j]
@@ -48,9 +57,7 @@ def _worker(rank, world, port, ret):
             ok &= n == 1000 + 37 * i
             ok &= bool(torch.equal(row[:n], torch.arange(n, dtype=torch.float32) + 10000.0 * i))
             ok &= float(row[n:].abs().max()) == 0.0
-    ret[rank] = ok
-    dist.barrier()
-    dist.destroy_process_group()
+    return ok
 
 
 def test_gather_audio_gloo_world2():
