@@ -104,6 +104,9 @@ def _declare(L):
     L.fy_llm_begin.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, i32, vp, i32, vp]
     L.fy_llm_step.argtypes = [vp, i32, vp, i32, vp, vp, i32p, vp]
     L.fy_llm_logp.argtypes = [vp, i32, f32p, vp]
+    L.fy_llm_set_decode_mode.argtypes = [vp, i32]
+    L.fy_llm_decode_mode.argtypes = [vp]
+    L.fy_debug_decode_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
 
 
 def tensor_table(weights):

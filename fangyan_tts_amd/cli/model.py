@@ -39,6 +39,13 @@ class CosyVoice3Model:
         self.llms = [LlmEngine(llm_weights, cfg.llm, max_batch=max_batch * self.lm_group, max_ctx=2 + max_text + max_prompt_tokens + max_tokens,
                                device=self.device, keep_weights=keep_llm_weights and i == 0) for i in range(max(1, n_llm))]
         self.llm = self.llms[0]
+        # Several LM handles decoding beside the flow decoder (tts_pipeline) want the one-launch-per-operation decode: its
+        # short kernels interleave with the other streams, while the persistent step holds 152 CUs for its whole duration
+        # and two of them never overlap (measured at batch 8: 86.6 ms per pipelined step against 102).  A single handle
+        # (tts, tts_batch, stream=True) uses the persistent step: lowest latency.
+        if len(self.llms) > 1:
+            for e in self.llms:
+                e.set_decode_mode(False)
         self.flow = FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device)
         self.hift = HiftEngine(hift_weights, cfg.hift, max_batch=max_batch, max_frames=2 * max_tokens, device=self.device)
         # The reference draws these buffers once at construction and never stores them in a checkpoint

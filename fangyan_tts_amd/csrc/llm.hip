@@ -10,6 +10,7 @@
 // per-sequence state (positions, counts, stop flags) on the device, so a step needs no host sync.
 #include "attn.h"
 #include "gemm.h"
+#include "llm_decode.h"
 #include "runtime.h"
 #include <algorithm>
 #include <math.h>
@@ -42,6 +43,8 @@ struct fy_llm {
     int B = 0;
     int step_next = 0, steps_cap = 0;      // fy_llm_begin / fy_llm_step: next decode step of the generation in progress, and its bound
     bool all_done = false;                 // every sequence of that generation has ended: further steps are no-ops
+    DecodePlan* dec = nullptr;             // persistent one-launch decode step (llm_decode.hip) when the architecture fits
+    int decode_mode = 1;                   // fy_llm_set_decode_mode: 1 = use it, 0 = one launch per operation
     int n_speech() const { return cfg.speech_tokens + 200; }
     int qkv_dim() const { return (cfg.q_heads + 2 * cfg.kv_heads) * cfg.head_dim; }
     size_t cache_layer() const { return (size_t)max_batch * cfg.kv_heads * max_ctx * cfg.head_dim; }
@@ -411,7 +414,7 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
     fy_llm* l = new fy_llm();
     if (cfg) l->cfg = *cfg; else fy_llm_default_config(&l->cfg);
     const fy_llm_config& c = l->cfg;
-    auto fail = [&](int code) { delete l; return code; };
+    auto fail = [&](int code) { if (l->dec) decode_destroy(l->dec); delete l; return code; };
     if (c.head_dim != 64 || c.q_heads % c.kv_heads != 0 || c.hidden % 8 != 0 || c.inter % 8 != 0 || c.q_heads * c.head_dim != c.hidden) {
         fy_set_error("fy_llm_create: unsupported architecture (hidden %d, heads %d/%d x %d)", c.hidden, c.q_heads, c.kv_heads, c.head_dim);
         return fail(FY_ERR_ARG);
@@ -425,6 +428,13 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
     const int H = c.hidden, Q = c.q_heads * 64, KV = c.kv_heads * 64, I = c.inter, NS = l->n_speech();
     const std::string P = "llm.model.model.";
     l->L.resize(c.layers);
+    TRYC(l->pool.alloc(&l->Kc, (size_t)c.layers * l->cache_layer()));
+    TRYC(l->pool.alloc(&l->Vc, (size_t)c.layers * l->cache_layer()));
+    {
+        DecodeShape ds;
+        ds.H = H; ds.I = I; ds.Hq = c.q_heads; ds.Hk = c.kv_heads; ds.layers = c.layers; ds.NS = NS; ds.max_ctx = max_ctx; ds.mb = max_batch; ds.eps = c.rms_eps;
+        if (decode_supported(ds)) TRYC(decode_create(&l->dec, ds, st));
+    }
     for (int i = 0; i < c.layers; ++i) {
         const std::string p = P + "layers." + std::to_string(i) + ".";
         LlmLayerW& k = l->L[i];
@@ -436,9 +446,13 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
         GETW(dw, p + "mlp.down_proj.weight", H, I);
         GETW(n1, p + "input_layernorm.weight", H); GETW(n2, p + "post_attention_layernorm.weight", H);
         // q, k, v rows concatenated; gate / up rows interleaved; all in the GEMV's fragment order
-        float* tmp = nullptr;
+        float *tmp = nullptr, *tmpg = nullptr;
         TRYC(l->pool.alloc(&k.bqkv, (size_t)(Q + 2 * KV)));
-        if (hipMalloc(&tmp, (size_t)2 * I * H * sizeof(float)) != hipSuccess) { fy_set_error("fy_llm_create: out of memory"); return fail(FY_ERR_HIP); }
+        if (hipMalloc(&tmp, (size_t)(Q + 2 * KV) * H * sizeof(float)) != hipSuccess || hipMalloc(&tmpg, (size_t)2 * I * H * sizeof(float)) != hipSuccess) {
+            if (tmp) (void)hipFree(tmp);
+            fy_set_error("fy_llm_create: out of memory");
+            return fail(FY_ERR_HIP);
+        }
         bool ok = hipMemcpyAsync(tmp, qw, (size_t)Q * H * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
                   hipMemcpyAsync(tmp + (size_t)Q * H, kw, (size_t)KV * H * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
                   hipMemcpyAsync(tmp + (size_t)(Q + KV) * H, vw, (size_t)KV * H * 4, hipMemcpyDeviceToDevice, st) == hipSuccess &&
@@ -447,11 +461,18 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
                   hipMemcpyAsync(k.bqkv + Q + KV, vb, KV * sizeof(float), hipMemcpyDeviceToDevice, st) == hipSuccess;
         int rc2 = ok ? to_packed(l, tmp, Q + 2 * KV, H, &k.wqkv, st) : FY_ERR_HIP;
         if (rc2 == FY_OK) {
-            hipLaunchKernelGGL(interleave_gu_k, dim3(4096), dim3(256), 0, st, gw, uw, tmp, I, H);
-            rc2 = to_packed(l, tmp, 2 * I, H, &k.wgu, st);
+            hipLaunchKernelGGL(interleave_gu_k, dim3(4096), dim3(256), 0, st, gw, uw, tmpg, I, H);
+            rc2 = to_packed(l, tmpg, 2 * I, H, &k.wgu, st);
+        }
+        if (rc2 == FY_OK && l->dec) {
+            DecodeLayerSrc ds;
+            ds.wqkv = tmp; ds.wo = ow; ds.wgu = tmpg; ds.wd = dw; ds.bqkv = k.bqkv; ds.ln1 = n1; ds.ln2 = n2;
+            ds.Kc = l->Kc + (size_t)i * l->cache_layer(); ds.Vc = l->Vc + (size_t)i * l->cache_layer();
+            rc2 = decode_pack_layer(l->dec, i, ds, st);
         }
         (void)hipStreamSynchronize(st);
         (void)hipFree(tmp);
+        (void)hipFree(tmpg);
         if (rc2 != FY_OK) { if (!ok) fy_set_error("fy_llm_create: weight copy failed"); return fail(rc2); }
         TRYC(to_packed(l, ow, H, Q, &k.wo, st));
         TRYC(to_packed(l, dw, H, I, &k.wd, st));
@@ -464,6 +485,7 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
         GETW(ew, P + "embed_tokens.weight", c.vocab, H);
         TRYC(copy_f32(l, nw, H, &l->norm_w, st));
         TRYC(to_packed(l, hw, NS, H, &l->w_head, st));
+        if (l->dec) TRYC(decode_pack_head(l->dec, hw, nw, st));
         TRYC(copy_f32(l, sw, (size_t)NS * H, &l->speech_emb, st));
         TRYC(to_bf16(l, ew, (size_t)c.vocab * H, &l->embed_tokens, st));
     }
@@ -478,8 +500,6 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
         }
     }
     const size_t R = l->max_rows, B = max_batch;
-    TRYC(l->pool.alloc(&l->Kc, (size_t)c.layers * l->cache_layer()));
-    TRYC(l->pool.alloc(&l->Vc, (size_t)c.layers * l->cache_layer()));
     TRYC(l->pool.alloc(&l->h, R * H)); TRYC(l->pool.alloc(&l->xn, R * H)); TRYC(l->pool.alloc(&l->qkv, R * l->qkv_dim()));
     TRYC(l->pool.alloc(&l->ao, R * H)); TRYC(l->pool.alloc(&l->act, (size_t)16)); TRYC(l->pool.alloc(&l->act_split, ((R + 7) / 8) * 24 * (size_t)I)); TRYC(l->pool.alloc(&l->hb, B * H));
     TRYC(l->pool.alloc(&l->logits, B * NS)); TRYC(l->pool.alloc(&l->partial, gemv_partial_floats((int)R, H, I) + 16));
@@ -506,6 +526,7 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
 
 extern "C" void fy_llm_destroy(fy_llm* l) {
     if (l && l->recent) (void)hipFree(l->recent);
+    if (l && l->dec) decode_destroy(l->dec);
     delete l;
 }
 
@@ -544,6 +565,7 @@ static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, 
     return FY_OK;
 }
 
+static int llm_sample(fy_llm* l, int B, int32_t* out_ids, int out_ld, int keep_step, hipStream_t st);
 static int llm_head_and_sample(fy_llm* l, int B, const float* rows, int32_t* out_ids, int out_ld, int keep_step, hipStream_t st) {
     const fy_llm_config& c = l->cfg;
     const int H = c.hidden, NS = l->n_speech();
@@ -551,6 +573,13 @@ static int llm_head_and_sample(fy_llm* l, int B, const float* rows, int32_t* out
     a.W = l->w_head; a.x = rows; a.ldx = H; a.R = B; a.N = NS; a.K = H; a.y = l->logits; a.ldy = NS;
     a.norm_w = l->norm_w; a.eps = c.rms_eps;
     FY_TRY(gemv_bf16w(a, st));
+    return llm_sample(l, B, out_ids, out_ld, keep_step, st);
+}
+
+// logits (B, n_speech) -> the sampler: token, stop flags, silent-token filter, next input embedding into h
+static int llm_sample(fy_llm* l, int B, int32_t* out_ids, int out_ld, int keep_step, hipStream_t st) {
+    const fy_llm_config& c = l->cfg;
+    const int H = c.hidden, NS = l->n_speech();
     FY_CHECK(NS <= 256 * 32, FY_ERR_ARG, "sample: %d logits exceed the kernel's register tile", NS);
     if (l->sampler == 1)
         hipLaunchKernelGGL(sample_ras_k, dim3(B), dim3(256), (size_t)NS * sizeof(float), st, l->logits, NS, c.speech_tokens, l->st, l->max_batch,
@@ -632,15 +661,25 @@ extern "C" int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t
     const int mb = l->max_batch, B = l->B;
     const int end = l->all_done ? l->step_next : (int)std::min<long>((long)l->step_next + n_steps, l->steps_cap);
     std::vector<int> done(mb, 0);
+    unsigned dec_status = 0;
     auto read_done = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (l->dec) FY_TRY(decode_status(l->dec, &dec_status, st));
         HIP_TRY(hipStreamSynchronize(st));
+        FY_CHECK(dec_status == 0, FY_ERR_STATE, "fy_llm_step: the decode kernel's grid hand-off timed out (its workgroups were not all resident: "
+                 "another persistent grid on the device?); set FY_LLM_PERSISTENT=0 to use the multi-launch path");
         return FY_OK;
     };
     int step = l->step_next;
+    const bool persistent = l->dec && l->decode_mode == 1 && B <= 8;
     for (; step < end; ++step) {
-        FY_TRY(llm_layers(l, B, l->seq_ids, l->st, true, st));
-        FY_TRY(llm_head_and_sample(l, B, l->h, out_ids, out_ld, step, st));
+        if (persistent) {                    // the 24 layers + llm_decoder of the step in one launch, then the sampler
+            FY_TRY(decode_step(l->dec, B, l->h, l->st, l->inv_freq, l->logits, st));
+            FY_TRY(llm_sample(l, B, out_ids, out_ld, step, st));
+        } else {
+            FY_TRY(llm_layers(l, B, l->seq_ids, l->st, true, st));
+            FY_TRY(llm_head_and_sample(l, B, l->h, out_ids, out_ld, step, st));
+        }
         if ((step & 7) == 7) {
             FY_TRY(read_done());
             bool all = true;
@@ -708,3 +747,17 @@ extern "C" int fy_llm_logp(fy_llm* l, int32_t step, float* dst, void* stream) {
                                hipMemcpyDeviceToDevice, st));
     return FY_OK;
 }
+
+// diagnostic, not part of the ABI header: phase time stamps of the persistent decode kernel's last launch
+extern "C" int fy_debug_decode_stamps(fy_llm* l, unsigned long long* out, int32_t n, void* stream) {
+    FY_CHECK(l && l->dec, FY_ERR_STATE, "fy_debug_decode_stamps: this handle has no persistent decode plan");
+    return decode_stamps(l->dec, out, n, (hipStream_t)stream);
+}
+
+extern "C" int fy_llm_set_decode_mode(fy_llm* l, int32_t mode) {
+    FY_CHECK(l && (mode == 0 || mode == 1), FY_ERR_ARG, "fy_llm_set_decode_mode: mode must be 0 (one launch per operation) or 1 (persistent step)");
+    l->decode_mode = mode;
+    return FY_OK;
+}
+
+extern "C" int fy_llm_decode_mode(const fy_llm* l) { return l && l->dec && l->decode_mode == 1 ? 1 : 0; }

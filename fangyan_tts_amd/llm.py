@@ -132,6 +132,15 @@ class LlmEngine:
         self._uniforms = u                                   # borrowed by the library until the next call
         check(_lib.lib().fy_llm_set_sampler(self._h, 1, u.data_ptr(), u.shape[1], top_k, top_p, win_size, tau_r))
 
+    def set_decode_mode(self, persistent: bool):
+        """True (default): one persistent launch per token step (lowest latency; holds most of the chip while it runs).
+        False: one launch per operation, whose short kernels interleave with other streams (what tts_pipeline uses)."""
+        check(_lib.lib().fy_llm_set_decode_mode(self._h, 1 if persistent else 0))
+
+    @property
+    def persistent(self) -> bool:
+        return bool(_lib.lib().fy_llm_decode_mode(self._h))
+
     def logp(self, step: int, B: int) -> torch.Tensor:
         buf = torch.empty(B, self.cfg.n_speech, device=self.device)
         check(_lib.lib().fy_llm_logp(self._h, step, buf.data_ptr(), self._stream()))

@@ -185,6 +185,14 @@ int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t out_ld, in
  * start of every fy_llm_generate call, one value per multinomial the reference would draw.                               */
 int fy_llm_set_sampler(fy_llm* l, int32_t kind, const float* uniforms, int64_t n_uniforms, int32_t top_k, float top_p,
                        int32_t win_size, float tau_r);
+/* How fy_llm_step runs a token step (Qwen2Encoder.forward_one_step + llm_decoder, llm/llm.py:246-258, 518).
+ * mode 1 (default when the architecture fits and the batch is <= 8): ONE persistent launch per token step - lowest latency,
+ * but its workgroups hold 152 CUs while they wait on each other, so concurrent streams (a flow decoder beside it, other LM
+ * handles) get the rest of the chip only; two such launches never overlap.  mode 0: one launch per operation (121 per step)
+ * - slower alone, but its short kernels interleave with other streams' work.  Token ids are identical in both modes.
+ * fy_llm_decode_mode returns the mode in effect (0 when the persistent kernel is not available for this handle).        */
+int fy_llm_set_decode_mode(fy_llm* l, int32_t mode);
+int fy_llm_decode_mode(const fy_llm* l);
 /* log_softmax of step `step` (0 = first generated token) of the last fy_llm_generate call, (B, speech_tokens+200).
  * Only the first FY_LLM_KEEP_LOGP steps are kept.                                                            */
 #define FY_LLM_KEEP_LOGP 4

@@ -23,14 +23,32 @@ def make(cfg, max_batch=4, max_ctx=512):
     return LlmEngine(sd, cfg, max_batch=max_batch, max_ctx=max_ctx)
 
 
+# every test runs on both decode paths: the persistent one-launch token step (llm_decode.hip) and one launch per operation
 @pytest.fixture(scope="module")
-def tiny():
+def _tiny():
     return make(LlmCfg.tiny())
 
 
 @pytest.fixture(scope="module")
-def full():
+def _full():
     return make(LlmCfg(), max_batch=2, max_ctx=256)
+
+
+def _mode(eng, persistent):
+    eng.set_sampler("greedy")
+    eng.set_decode_mode(persistent)
+    assert eng.persistent == persistent, "the persistent decode kernel must be available for both test architectures"
+    return eng
+
+
+@pytest.fixture(params=[True, False], ids=["persistent", "per-op"])
+def tiny(_tiny, request):
+    return _mode(_tiny, request.param)
+
+
+@pytest.fixture(params=[True, False], ids=["persistent", "per-op"])
+def full(_full, request):
+    return _mode(_full, request.param)
 
 
 def run_cases(eng, f, cases, cap, tagname):
