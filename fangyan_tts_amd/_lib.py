@@ -104,6 +104,13 @@ def _declare(L):
     L.fy_llm_begin.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, i32, vp, i32, vp]
     L.fy_llm_step.argtypes = [vp, i32, vp, i32, vp, vp, i32p, vp]
     L.fy_llm_logp.argtypes = [vp, i32, f32p, vp]
+    L.fy_prompt_mel_create.argtypes = [C.POINTER(vp), i32, vp]
+    L.fy_prompt_mel_destroy.argtypes = [vp]
+    L.fy_prompt_mel_destroy.restype = None
+    L.fy_prompt_mel_frames.argtypes = [i32]
+    L.fy_prompt_mel_run.argtypes = [vp, vp, i32, vp, i32, vp]
+    L.fy_stream_create_masked.argtypes = [C.POINTER(vp), C.POINTER(C.c_uint32), i32]
+    L.fy_stream_destroy.argtypes = [vp]
     L.fy_llm_set_decode_mode.argtypes = [vp, i32]
     L.fy_llm_decode_mode.argtypes = [vp]
     L.fy_debug_decode_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]

@@ -9,9 +9,11 @@
 Model dir layout is the reference's: cosyvoice3.yaml, llm.pt, flow.pt, hift.pt (+ the frontend's tokenizer / ONNX
 files).  Architecture sizes are read off the checkpoint tensors themselves; the yaml contributes only scalars.
 
-The text / audio frontend (tokenizer, speech tokenizer, x-vector, prompt mel: cli/frontend.py) is SURVEY 8 f1, not
-built this round: pass `frontend=` (any object with the reference frontend's methods) or expect a clear error at the
-first inference call.  Everything from `model_input` on runs on the GPU engines.
+The text / audio frontend is fangyan_tts_amd/cli/frontend.py (`CosyVoiceFrontEnd`: text normalisation + splitting, the
+model_input dicts, the prompt mel on the GPU).  Built by default from <model_dir>/CosyVoice-BlankEN (Qwen tokenizer files)
+and spk2info.pt; the two ONNX models of the reference's frontend (speech tokenizer, campplus x-vector) need onnxruntime,
+which this image lacks: pass them as callables (`speech_tokenizer=`, `spk_embedder=`) or pass a whole `frontend=` object.
+Everything from `model_input` on runs on the GPU engines.
 """
 from __future__ import annotations
 
@@ -86,19 +88,29 @@ def infer_cfg(llm_sd, flow_sd, hift_sd, conf: Dict) -> ModelCfg:
     return ModelCfg(llm, flow, hift)
 
 
-class _MissingFrontEnd:
-    """Stands in until cli/frontend.py's counterpart exists."""
+class _LazyFrontEndError:
+    """Stands in when the default frontend could not be built (no tokenizer files in the model dir): the reason is raised at the
+    first call that needs the frontend, as the reference would fail in CosyVoiceFrontEnd.__init__."""
     spk2info: Dict = {}
 
+    def __init__(self, err: BaseException):
+        self._err = err
+
     def __getattr__(self, name):
-        raise NotImplementedError(
-            "the text/audio frontend (tokenizer, speech_tokenizer_v3.onnx, campplus.onnx, prompt mel) is not built yet; "
-            "pass frontend=<object with text_normalize / frontend_zero_shot / frontend_instruct2 / frontend_cross_lingual>")
+        raise RuntimeError(f"the frontend could not be built: {self._err}; pass frontend=<object with text_normalize / "
+                           "frontend_zero_shot / frontend_instruct2 / ...> or a tokenizer")
 
 
 class CosyVoice3:
-    def __init__(self, model_dir, load_trt=False, load_vllm=False, fp16=False, trt_concurrent=1, frontend=None,
-                 max_batch: int = 1, max_tokens: int = 1500, max_prompt_tokens: int = 750, device=None, sampler: str = "ras"):
+    def __init__(self, model_dir, load_trt=False, load_vllm=False, fp16=False, trt_concurrent=1, frontend=None, tokenizer=None,
+                 speech_tokenizer=None, spk_embedder=None,
+                 max_batch: int = 1, max_tokens: int = 1600, max_prompt_tokens: int = 750, max_text: int = 160, device=None,
+                 sampler: str = "ras", concurrency: int = 1):
+        """Capacities (the engines are sized once): max_text bounds prompt-text + text ids of a segment (text_normalize cuts
+        segments at 80 tokens, cli/frontend.py:151), max_tokens the generated speech tokens (the LM's own bound is 20 x the
+        text length, llm.py:744: 1600 for an 80-token segment), max_prompt_tokens the prompt (30 s = 750 tokens,
+        cli/frontend.py:97).  concurrency > 1 builds that many independent engine sets so that many threads can be inside
+        tts() at once (runtime/python/grpc/server.py:68-69); with 1, concurrent calls take turns."""
         self.model_dir, self.fp16 = model_dir, fp16
         if not os.path.exists(model_dir):
             raise ValueError("{} not found (no network here: the reference would call snapshot_download)".format(model_dir))
@@ -113,12 +125,21 @@ class CosyVoice3:
         sds[2] = {k.replace("generator.", ""): v for k, v in sds[2].items()}          # cli/model.py:71
         self.cfg = infer_cfg(*sds, conf)
         assert self.cfg.llm.speech_tokens == self.cfg.flow.vocab, "llm.pt and flow.pt disagree on the speech vocabulary"
-        self.frontend = frontend if frontend is not None else _MissingFrontEnd()
         dev = device or torch.device("cuda", torch.cuda.current_device())
+        if frontend is None:
+            # cli/cosyvoice.py:204-209: CosyVoiceFrontEnd(get_tokenizer, feat_extractor, campplus.onnx, speech_tokenizer_v3.onnx, spk2info.pt)
+            from .frontend import CosyVoiceFrontEnd, load_qwen_tokenizer
+            try:
+                frontend = CosyVoiceFrontEnd(tokenizer if tokenizer is not None else load_qwen_tokenizer(model_dir),
+                                             speech_tokenizer=speech_tokenizer, spk_embedder=spk_embedder,
+                                             spk2info="{}/spk2info.pt".format(model_dir), device=dev)
+            except (FileNotFoundError, OSError) as e:
+                frontend = _LazyFrontEndError(e)
+        self.frontend = frontend
         to_dev = lambda sd: {k: v.to(dev, torch.float32).contiguous() for k, v in sd.items() if "lm_head" not in k}
         self.model = CosyVoice3Model(to_dev(sds[0]), to_dev(sds[1]), to_dev(sds[2]), self.cfg, device=dev, max_batch=max_batch,
-                                     max_tokens=max_tokens, max_prompt_tokens=max_prompt_tokens, fp16=fp16, keep_llm_weights=True,
-                                     sampler=sampler)
+                                     max_tokens=max_tokens, max_prompt_tokens=max_prompt_tokens, max_text=max_text, fp16=fp16,
+                                     keep_llm_weights=True, sampler=sampler, concurrency=concurrency)
 
     # ---- speaker bookkeeping (cli/cosyvoice.py:64-78) ------------------------------------------------
     def list_available_spks(self):

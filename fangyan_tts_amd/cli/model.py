@@ -18,13 +18,21 @@ from ..llm import LlmEngine
 from ..spec import ModelCfg, SAMPLE_RATE
 
 
+class _Lane:
+    """One set of single-threaded engine handles (+ the stream its calls run on; None = the caller's current stream)."""
+
+    def __init__(self, llm, flow, hift, stream):
+        self.llm, self.flow, self.hift, self.stream = llm, flow, hift, stream
+        self.uniforms = None
+
+
 class CosyVoice3Model:
     def __init__(self, llm_weights: Dict[str, torch.Tensor], flow_weights: Dict[str, torch.Tensor],
                  hift_weights: Dict[str, torch.Tensor], cfg: ModelCfg = ModelCfg(), device: Optional[torch.device] = None,
                  max_batch: int = 8, max_text: int = 128, max_prompt_tokens: int = 800, max_tokens: int = 800,
                  rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
                  sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False, n_llm: int = 1,
-                 sampler: str = "greedy", sampler_seed: int = 1986, lm_group: int = 1):
+                 sampler: str = "greedy", sampler_seed: int = 1986, lm_group: int = 1, concurrency: int = 1):
         if not torch.cuda.is_available():
             raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -48,6 +56,22 @@ class CosyVoice3Model:
                 e.set_decode_mode(False)
         self.flow = FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device)
         self.hift = HiftEngine(hift_weights, cfg.hift, max_batch=max_batch, max_frames=2 * max_tokens, device=self.device)
+        # The reference lets several threads enter tts() on one model object (a gRPC pool, runtime/python/grpc/server.py:68-69;
+        # per-call state keyed by uuid, cli/model.py:330-333).  An engine handle is single-threaded, so concurrent calls each
+        # take a LANE - an own (LM, flow, vocoder) handle set and stream; `concurrency` lanes exist (the reference's
+        # trt_concurrent plays this role for its estimator contexts, cli/model.py:94-99).  With one lane calls take turns.
+        import queue as _q
+        self.lanes = [_Lane(self.llm, self.flow, self.hift, None)]
+        for _ in range(1, max(1, concurrency)):
+            self.lanes.append(_Lane(
+                LlmEngine(llm_weights, cfg.llm, max_batch=max_batch, max_ctx=2 + max_text + max_prompt_tokens + max_tokens, device=self.device),
+                FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device),
+                HiftEngine(hift_weights, cfg.hift, max_batch=max_batch, max_frames=2 * max_tokens, device=self.device),
+                torch.cuda.Stream(device=self.device)))
+        self._free = _q.Queue()
+        for ln in self.lanes:
+            self._free.put(ln)
+        self._count_mu = threading.Lock()
         # The reference draws these buffers once at construction and never stores them in a checkpoint
         # (flow_matching.py:199-200; generator.py:223-226); pass them in to reproduce a given instance.
         g = torch.Generator().manual_seed(0)
@@ -56,18 +80,92 @@ class CosyVoice3Model:
         n = 2 * max_tokens * cfg.hift.upsample_total
         self.sine_noise = (sine_noise if sine_noise is not None else torch.rand(1, n, 9, generator=g)).to(self.device).contiguous()
         self.token_hop_len = 25
+        # precision modes of the two back stages (include/fy_cosy3.h): 0 = bf16 MFMA operands (default); FY_PRECISE = fp32-class
+        # (split operands, fp32 attention); for the vocoder also FY_DIRECT = exact fp32 convolutions.  Verification modes.
+        self.flow_flags, self.hift_flags = 0, 0
         self.lock = threading.Lock()          # the engines' handles are single-threaded
         # "greedy": the deterministic rule of SURVEY 8 a4.  "ras": the reference's default repetition-aware sampling; its
         # multinomial draws come from fresh uniforms (one row per sequence slot) drawn before every LM call
-        self.sampler = sampler
-        self._sampler_gen = torch.Generator(device=self.device).manual_seed(sampler_seed)
+        self.sampler, self.sampler_seed = sampler, sampler_seed
         self._uniforms = [torch.zeros(max_batch * self.lm_group, 4 * max_tokens + 256, device=self.device) for _ in self.llms] if sampler == "ras" else None
+        self._n_batches = 0                   # batches decoded so far: batch k draws from a generator seeded (sampler_seed, k)
+        self.max_text = max_text
         assert sampler in ("greedy", "ras")
 
-    def _arm_sampler(self, i: int = 0):
+    def _arm_lane_sampler(self, ln, k: int, nb: int):
         if self.sampler == "ras":
-            self._uniforms[i].uniform_(0.0, 1.0, generator=self._sampler_gen)
-            self.llms[i].set_sampler("ras", self._uniforms[i])
+            if ln.uniforms is None:
+                ln.uniforms = torch.zeros(self.max_batch, 4 * self.max_tokens + 256, device=self.device)
+            g = torch.Generator(device=self.device).manual_seed((self.sampler_seed << 20) + int(k))
+            ln.uniforms[:nb].uniform_(0.0, 1.0, generator=g)
+            ln.llm.set_sampler("ras", ln.uniforms)
+
+    def _arm_sampler(self, i: int = 0, batch_ids: Sequence[int] = (0,), sizes: Optional[Sequence[int]] = None):
+        """Uniforms for the LM call of handle i that decodes the batches `batch_ids` (global batch counters): each batch's rows
+        come from its own generator seeded (sampler_seed, batch counter), so what a batch draws does not depend on which
+        handle, thread or call decodes it - tts_pipeline reproduces a sequence of tts_batch calls under "ras" too."""
+        if self.sampler == "ras":
+            u, o = self._uniforms[i], 0
+            for j, k in enumerate(batch_ids):             # batch j of the call occupies the sequence slots o .. o + its size
+                nb = self.max_batch if sizes is None else int(sizes[j])
+                g = torch.Generator(device=self.device).manual_seed((self.sampler_seed << 20) + int(k))
+                u[o: o + nb].uniform_(0.0, 1.0, generator=g)
+                o += nb
+            self.llms[i].set_sampler("ras", u)
+
+    def _take_lane(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            ln = self._free.get()                              # waits while every lane is busy
+            try:
+                if ln.stream is None:
+                    yield ln
+                else:
+                    ln.stream.wait_stream(torch.cuda.current_stream(self.device))
+                    with torch.cuda.stream(ln.stream):
+                        yield ln
+                    ln.stream.synchronize()
+            finally:
+                self._free.put(ln)
+        return cm()
+
+    def _take_all_lanes(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            got = [self._free.get() for _ in self.lanes]      # the pipeline owns every handle while it runs
+            try:
+                yield
+            finally:
+                for ln in got:
+                    self._free.put(ln)
+        return cm()
+
+    def _next_batch_ids(self, n: int = 1):
+        with self._count_mu:
+            k = self._n_batches
+            self._n_batches += n
+        return k
+
+    def _check_capacity(self, inputs, max_len):
+        """The engines were sized at construction; say so up front instead of failing after the whole LM decode."""
+        z = torch.zeros(1, 0, dtype=torch.int32)
+        for b, d in enumerate(inputs):
+            n_text = d["text"].reshape(-1).shape[0] + d.get("prompt_text", z).reshape(-1).shape[0]
+            n_ps = d.get("llm_prompt_speech_token", z).reshape(-1).shape[0]
+            n_fp = d["flow_prompt_speech_token"].reshape(-1).shape[0]
+            cap = int(max_len[b]) if max_len is not None else 20 * d["text"].reshape(-1).shape[0]
+            if n_text > self.max_text:
+                raise ValueError(f"utterance {b}: {n_text} text + prompt-text ids, the model was built for max_text={self.max_text}")
+            if max(n_ps, n_fp) > self.max_prompt_tokens:
+                raise ValueError(f"utterance {b}: {max(n_ps, n_fp)} prompt speech tokens, the model was built for "
+                                 f"max_prompt_tokens={self.max_prompt_tokens}")
+            if cap > self.max_tokens:
+                raise ValueError(f"utterance {b}: up to {cap} speech tokens (20 x the text length, llm.py:744), the model was built "
+                                 f"for max_tokens={self.max_tokens}; pass max_len or build with a larger max_tokens")
 
     # ------------------------------------------------------------------ batched path
     @torch.inference_mode()
@@ -81,15 +179,17 @@ class CosyVoice3Model:
         text = [d["text"].reshape(-1).tolist() for d in inputs]
         ptext = [d.get("prompt_text", z).reshape(-1).tolist() for d in inputs]
         pspeech = [d.get("llm_prompt_speech_token", z).reshape(-1).tolist() for d in inputs]
-        with self.lock:
-            self._arm_sampler()
-            out, out_n, _ = self.llm.generate(text, ptext, pspeech, min_len=min_len, max_len=max_len)
+        self._check_capacity(inputs, max_len)
+        with self._take_lane() as ln:
+            self._arm_lane_sampler(ln, self._next_batch_ids(), B)
+            out, out_n, _ = ln.llm.generate(text, ptext, pspeech, min_len=min_len, max_len=max_len)
             n_tok = out_n.cpu().tolist()
             if min(n_tok) < 1:
                 raise RuntimeError("the language model emitted no speech token for an utterance")
-            wav, samples = self._token2wav(inputs, out, n_tok, speed)
+            wav, samples = self._token2wav(inputs, out, n_tok, speed, ln)
+            res = wav if keep_on_device else wav.cpu()
         toks = [out[b, : n_tok[b]] for b in range(B)]
-        return (wav if keep_on_device else wav.cpu()), samples, toks
+        return res, samples, toks
 
     # ------------------------------------------------------------------ pipelined batches
     @torch.inference_mode()
@@ -122,6 +222,18 @@ class CosyVoice3Model:
         s_fv = pool[0]
         qs = [queue.Queue(maxsize=2 * self.lm_group) for _ in range(n_prod)]
         z = torch.zeros(1, 0, dtype=torch.int32)
+        stop, box = th.Event(), {}
+        for bi, inputs in enumerate(batches):
+            self._check_capacity(inputs, max_len[bi] if max_len is not None else None)
+
+        def put(q, item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def producer(pi):
             llm, q = self.llms[pi], qs[pi]
@@ -130,6 +242,8 @@ class CosyVoice3Model:
                 with torch.cuda.device(dev), torch.cuda.stream(lm_stream):
                     G = self.lm_group
                     for g0 in range(pi * G, len(batches), n_prod * G):
+                        if stop.is_set():
+                            return
                         group = list(range(g0, min(g0 + G, len(batches))))
                         text, ptext, pspeech, mn, mx = [], [], [], [], []
                         for bi in group:
@@ -139,7 +253,7 @@ class CosyVoice3Model:
                             pspeech += [d.get("llm_prompt_speech_token", z).reshape(-1).tolist() for d in inputs]
                             mn += list(min_len[bi]) if min_len is not None else [int(len(d["text"].reshape(-1)) * 2) for d in inputs]
                             mx += list(max_len[bi]) if max_len is not None else [int(len(d["text"].reshape(-1)) * 20) for d in inputs]
-                        self._arm_sampler(pi)
+                        self._arm_sampler(pi, [box["base"] + bi for bi in group], [len(batches[bi]) for bi in group])
                         t0 = time.perf_counter()
                         out, out_n, _ = llm.generate(text, ptext, pspeech, min_len=mn, max_len=mx)
                         n_tok = out_n.cpu().tolist()              # synchronises the LM stream: the ids are complete
@@ -148,16 +262,18 @@ class CosyVoice3Model:
                         o = 0
                         for bi in group:
                             nb = len(batches[bi])
-                            q.put((batches[bi], out[o: o + nb], n_tok[o: o + nb]))
+                            if not put(q, (batches[bi], out[o: o + nb], n_tok[o: o + nb])):
+                                return
                             o += nb
             except BaseException as e:                             # surfaces in the consumer
-                q.put(e)
+                put(q, e)
 
         threads = [th.Thread(target=producer, args=(i,), daemon=True) for i in range(n_prod)]
-        with self.lock:
+        with self._take_all_lanes():
+            box["base"] = self._next_batch_ids(len(batches))
             for t in threads:
                 t.start()
-            with torch.cuda.stream(s_fv):
+            try:
                 for bi in range(len(batches)):
                     t0 = time.perf_counter()
                     item = qs[(bi // self.lm_group) % n_prod].get()
@@ -167,14 +283,28 @@ class CosyVoice3Model:
                     inputs, out, n_tok = item
                     if min(n_tok) < 1:
                         raise RuntimeError("the language model emitted no speech token for an utterance")
-                    wav, samples = self._token2wav(inputs, out, n_tok, 1.0)
+                    with torch.cuda.stream(s_fv):
+                        wav, samples = self._token2wav(inputs, out, n_tok, 1.0)
+                        res = (wav if keep_on_device else wav.cpu())
                     s_fv.synchronize()
                     if trace:
                         print(f"[pipe] batch {bi}: waited {1e3 * (t1 - t0):.1f} ms for ids, flow+vocoder {1e3 * (time.perf_counter() - t1):.1f} ms",
                               file=sys.stderr)
-                    yield (wav if keep_on_device else wav.cpu()), samples, [out[b, : n_tok[b]] for b in range(len(inputs))]
-            for t in threads:
-                t.join()
+                    # yielded OUTSIDE the stream context: the caller's own torch work (an all-gather, a copy) stays on its stream
+                    yield res, samples, [out[b, : n_tok[b]] for b in range(len(inputs))]
+            finally:
+                # an abandoned or failed generator must not leave producers inside the single-threaded LM handles: tell them
+                # to stop, empty the queues so none stays parked in put(), and join them before the lock is released
+                stop.set()
+                for t in threads:
+                    while t.is_alive():
+                        for q in qs:
+                            try:
+                                while True:
+                                    q.get_nowait()
+                            except queue.Empty:
+                                pass
+                        t.join(timeout=0.05)
 
     def prepare_pipeline(self, flow_cu_exclude: Optional[int] = None):
         """Place the pipeline's streams now (otherwise the first tts_pipeline call does it, ~0.1-0.4 s)."""
@@ -236,7 +366,7 @@ class CosyVoice3Model:
         key = (exclude, only, tag)
         if key not in cache:
             import ctypes
-            hip = ctypes.CDLL("libamdhip64.so")
+            from .. import _lib
             n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
             words = (ctypes.c_uint32 * ((n_cu + 31) // 32))(*([0] * ((n_cu + 31) // 32)))
             for i in range(n_cu):
@@ -245,13 +375,25 @@ class CosyVoice3Model:
                     words[i // 32] |= 1 << (i % 32)
             st = ctypes.c_void_p()
             with torch.cuda.device(self.device):
-                rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(words), words)
-            if rc != 0:
-                raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {rc}")
+                # created by the HIP runtime libfy_cosy3 (and torch) are bound to, not by a second copy loaded by name
+                rc = _lib.lib().fy_stream_create_masked(ctypes.byref(st), words, len(words))
+            if rc != 0:                                      # no CU masking on this device / runtime: an ordinary stream
+                cache[key] = torch.cuda.Stream(device=self.device)
+                return cache[key]
+            self.__dict__.setdefault("_masked_raw", []).append(st.value)
             cache[key] = torch.cuda.ExternalStream(st.value, device=self.device)
         return cache[key]
 
-    def _token2wav(self, inputs, out, n_tok, speed):
+    def close(self):
+        """Release what the engines do not own themselves (the CU-masked streams)."""
+        from .. import _lib
+        for raw in self.__dict__.pop("_masked_raw", []):
+            _lib.lib().fy_stream_destroy(raw)
+        self.__dict__.pop("_masked_streams", None)
+        self.__dict__.pop("_pipe_stream_sets", None)
+
+    def _token2wav(self, inputs, out, n_tok, speed, ln=None):
+        ln = ln or self.lanes[0]
         B = len(inputs)
         fp = [d["flow_prompt_speech_token"].reshape(-1) for d in inputs]
         pf = [d["prompt_speech_feat"].reshape(-1, 80) for d in inputs]
@@ -262,13 +404,14 @@ class CosyVoice3Model:
             ptok[b, : len(fp[b])] = fp[b].to(torch.int32)
             pfeat[b, : pf[b].shape[0]] = pf[b]
         emb = torch.cat([d["flow_embedding"].reshape(1, -1) for d in inputs]).float()
-        mel = self.flow.inference(out, n_tok, ptok, [len(t) for t in fp], pfeat, [f.shape[0] for f in pf], emb, self.rand_noise)
+        mel = ln.flow.inference(out, n_tok, ptok, [len(t) for t in fp], pfeat, [f.shape[0] for f in pf], emb, self.rand_noise,
+                                flags=self.flow_flags)
         frames = [2 * n for n in n_tok]
         if speed != 1.0:                                    # cli/model.py:435-437
             assert B == 1, "speed change only supports a single utterance"
-            mel = self.flow.speed(mel, speed)
+            mel = ln.flow.speed(mel, speed)
             frames = [mel.shape[2]]
-        wav, _ = self.hift.inference(mel, self.rand_ini, self.sine_noise, frames=frames)
+        wav, _ = ln.hift.inference(mel, self.rand_ini, self.sine_noise, frames=frames, flags=self.hift_flags)
         self.last_mel, self.last_frames = mel, frames        # kept for parity tests / debugging
         return wav, [f * self.cfg.hift.upsample_total for f in frames]
 
@@ -296,11 +439,12 @@ class CosyVoice3Model:
         pfeat = pf if n_pf else torch.zeros(1, 1, 80)
         look, hop0 = self.cfg.flow.pre_lookahead, self.token_hop_len
         up = self.cfg.hift.upsample_total
-        with self.lock:
+        self._check_capacity([d], None)
+        with self._take_lane() as ln:
             if source_tokens is None:
-                self._arm_sampler()
-                out, _, _ = self.llm.begin(text, ptext, pspeech)
-                (n,), (done,) = self.llm.step(0)
+                self._arm_lane_sampler(ln, self._next_batch_ids(), 1)
+                out, _, _ = ln.llm.begin(text, ptext, pspeech)
+                (n,), (done,) = ln.llm.step(0)
             else:                                               # vc_job (cli/model.py:131-133): the token list is given, complete
                 out = source_tokens.reshape(1, -1).to(self.device, torch.int32)
                 n, done = out.shape[1], True
@@ -308,19 +452,19 @@ class CosyVoice3Model:
             offset, speech_offset, mel_all = 0, 0, None
 
             def token2wav(n_in, offset, mel_all, speech_offset, streaming, finalize):
-                mel = self.flow.inference(out[:, :n_in], [n_in], ptok, [n_fp], pfeat, [n_pf], emb, self.rand_noise,
-                                          streaming=streaming, finalize=finalize)
+                mel = ln.flow.inference(out[:, :n_in], [n_in], ptok, [n_fp], pfeat, [n_pf], emb, self.rand_noise,
+                                        streaming=streaming, finalize=finalize, flags=self.flow_flags)
                 valid = 2 * (n_in if finalize else n_in - look)
                 mel = mel[:, :, 2 * offset: valid]
                 mel_all = mel if mel_all is None else torch.cat([mel_all, mel], dim=2)
-                wav, _ = self.hift.inference(mel_all.contiguous(), self.rand_ini, self.sine_noise, finalize=finalize)
+                wav, _ = ln.hift.inference(mel_all.contiguous(), self.rand_ini, self.sine_noise, finalize=finalize, flags=self.hift_flags)
                 end = up * (mel_all.shape[2] if finalize else mel_all.shape[2] - 8)
                 return wav[:, speech_offset:end], mel_all, end
 
             while True:
                 need = offset + (hop0 + pad if offset == 0 else hop0) + look
                 while n < need and not done:                # the silent-token filter may drop tokens: ask again until enough
-                    (n,), (done,) = self.llm.step(need - n)
+                    (n,), (done,) = ln.llm.step(need - n)
                 if n < need:
                     break
                 wav, mel_all, speech_offset = token2wav(need, offset, mel_all, speech_offset, True, False)
@@ -353,10 +497,11 @@ class CosyVoice3Model:
             return
         if vc:
             inp = dict(flow_prompt_speech_token=flow_prompt_speech_token, prompt_speech_feat=prompt_speech_feat, flow_embedding=flow_embedding)
-            with self.lock:
+            with self._take_lane() as ln:
                 out = source_speech_token.reshape(1, -1).to(self.device, torch.int32)
-                wav, samples = self._token2wav([inp], out, [out.shape[1]], speed)
-            yield {"tts_speech": wav.cpu()[:, : samples[0]]}
+                wav, samples = self._token2wav([inp], out, [out.shape[1]], speed, ln)
+                res = wav.cpu()[:, : samples[0]]
+            yield {"tts_speech": res}
             return
         wav, samples, _ = self.tts_batch([dict(text=text, prompt_text=prompt_text, llm_prompt_speech_token=llm_prompt_speech_token,
                                                flow_prompt_speech_token=flow_prompt_speech_token,

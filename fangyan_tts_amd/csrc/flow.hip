@@ -37,6 +37,8 @@ struct fy_flow {
     int *tok_all, *seq_len, *blen;     // blen: [5][max_batch] = n_all tokens, T, pmel, prompt tokens, tokens PreLookahead outputs
     float *emb, *pre_a, *mu_tok, *spks, *x, *mu, *cond, *h, *c1, *v, *temb, *tsil, *gpart;
     bf16_t *a_in, *xn, *qkv, *ao, *ff;
+    // fp32 operands of the fp32-class mode (FY_PRECISE), allocated on its first use
+    float *a_in32 = nullptr, *xn32 = nullptr, *qkv32 = nullptr, *ao32 = nullptr, *ff32 = nullptr;
     ~fy_flow() { conv_free(pre1); conv_free(pre2); conv_free(pos1); conv_free(pos2); }
 };
 
@@ -98,7 +100,7 @@ __global__ void flow_setup_k(const float* __restrict__ mu_tok, const float* __re
 // InputEmbedding concat [x, cond, mu, spks] (dit.py:91-96) for the conditional row and [x, 0, 0, 0]
 // for the CFG row (flow_matching.py:95-101), as the bf16 A operand of the input projection.
 __global__ void dit_assemble_k(const float* __restrict__ x, const float* __restrict__ cond, const float* __restrict__ mu, const float* __restrict__ spks,
-                               const int* __restrict__ T, bf16_t* __restrict__ a, int Tmax, int C) {
+                               const int* __restrict__ T, bf16_t* __restrict__ a, float* __restrict__ a32, int Tmax, int C) {
     int s = blockIdx.y, t = blockIdx.x, b = s >> 1, cfg = s & 1;
     int i = threadIdx.x;                     // 0 .. 4C
     if (i >= 4 * C) return;
@@ -109,16 +111,17 @@ __global__ void dit_assemble_k(const float* __restrict__ x, const float* __restr
         if (part == 0) v = x[o + c];
         else if (!cfg) v = part == 1 ? cond[o + c] : (part == 2 ? mu[o + c] : spks[(long)b * C + c]);
     }
-    a[((long)s * Tmax + t) * 4 * C + i] = f32_to_bf16(v);
+    if (a32) a32[((long)s * Tmax + t) * 4 * C + i] = v;          // fp32-class mode (FY_PRECISE): the operand is split on the fly
+    else a[((long)s * Tmax + t) * 4 * C + i] = f32_to_bf16(v);
 }
 
 // LayerNorm(eps 1e-6, no affine) * (1 + scale) + shift -> bf16 (modules.py:238-243, 524, 262-264). One wave per row.
 __global__ __launch_bounds__(256) void ln_mod_k(const float* __restrict__ h, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                bf16_t* __restrict__ out, int M, int D) {
+                                                bf16_t* __restrict__ out, float* __restrict__ out32, int M, int D) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const float* p = h + (long)row * D;
-    if ((D & 255) == 0 && D <= 1024) {                       // 16-byte loads, 8-byte stores: four columns per lane and pass
+    if ((D & 255) == 0 && D <= 1024 && !out32) {                       // 16-byte loads, 8-byte stores: four columns per lane and pass
         const int per4 = D / 256;                            // <= 4
         float4 v[4];
         float s = 0.f;
@@ -164,9 +167,53 @@ __global__ __launch_bounds__(256) void ln_mod_k(const float* __restrict__ h, con
     for (int i = 0; i < 16; ++i) {
         if (i < per) {
             int c = lane + 64 * i;
-            out[(long)row * D + c] = f32_to_bf16((v[i] - mean) * rstd * (1.f + scale[c]) + shift[c]);
+            const float y = (v[i] - mean) * rstd * (1.f + scale[c]) + shift[c];
+            if (out32) out32[(long)row * D + c] = y; else out[(long)row * D + c] = f32_to_bf16(y);
         }
     }
+}
+
+// fp32 attention for the fp32-class mode (FY_PRECISE): one wave per query row; qkv fp32 [row][3*inner] = [q | k | v],
+// key-padding mask (key < len), optional chunk mask key < (query / chunk + 1) * chunk, rows beyond the length zeroed
+// (modules.py:391-401).  A verification path: no tiling, every query re-reads its sequence's keys from L2.
+__global__ __launch_bounds__(256) void dit_attention_f32_k(const float* __restrict__ qkv, float* __restrict__ out, const int* __restrict__ seq_len,
+                                                            int Tmax, int H, int chunk) {
+    extern __shared__ float at_sh[];                        // [4 waves][64 q + Tmax scores]
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + wid, h = blockIdx.y, s = blockIdx.z;
+    if (t >= Tmax) return;
+    const int inner = H * 64, ld = 3 * inner, len = seq_len[s];
+    float* qs = at_sh + wid * (64 + Tmax);
+    float* sc = qs + 64;
+    float* o = out + ((long)s * Tmax + t) * inner + h * 64;
+    if (t >= len) { o[lane] = 0.f; return; }
+    const float* base = qkv + (long)s * Tmax * ld;
+    qs[lane] = base[(long)t * ld + h * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    const int lim = chunk > 0 ? min(len, (t / chunk + 1) * chunk) : len;
+    float mx = -3.0e38f;
+    for (int j = lane; j < lim; j += 64) {
+        const float4* kr = reinterpret_cast<const float4*>(base + (long)j * ld + inner + h * 64);
+        float a = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < 16; ++d4) {
+            const float4 k4 = kr[d4];
+            a = fmaf(qs[d4 * 4 + 0], k4.x, a); a = fmaf(qs[d4 * 4 + 1], k4.y, a);
+            a = fmaf(qs[d4 * 4 + 2], k4.z, a); a = fmaf(qs[d4 * 4 + 3], k4.w, a);
+        }
+        a *= 0.125f;
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < lim; j += 64) { const float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    float acc = 0.f;
+    const float* vb = base + 2 * inner + h * 64 + lane;
+    for (int j = 0; j < lim; ++j) acc = fmaf(sc[j], vb[(long)j * ld], acc);
+    o[lane] = acc / sum;
 }
 
 // CFG mix and Euler update, flow_matching.py:114-118
@@ -374,15 +421,31 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
 
 extern "C" void fy_flow_destroy(fy_flow* f) { delete f; }
 
+// fp32 operand buffers of the fp32-class mode, sized for the handle's capacity, on first use
+static int ensure_precise(fy_flow* f) {
+    if (f->xn32) return FY_OK;
+    const fy_flow_config& c = f->cfg;
+    const size_t M = (size_t)2 * f->max_batch * f->Tmax, D = c.dim, inner = (size_t)c.heads * c.head_dim, FF = D * c.ff_mult;
+    FY_TRY(f->pool.alloc(&f->a_in32, M * 4 * c.mel)); FY_TRY(f->pool.alloc(&f->qkv32, M * 3 * inner));
+    FY_TRY(f->pool.alloc(&f->ao32, M * inner)); FY_TRY(f->pool.alloc(&f->ff32, M * FF)); FY_TRY(f->pool.alloc(&f->xn32, M * D));
+    return FY_OK;
+}
+
 // ---- estimator ----------------------------------------------------------------------------------------
 // One DiT.forward over nseq sequences whose bf16 input rows are in f->a_in; result rows (fp32, C wide) in f->v.
 static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming, uint32_t flags, hipStream_t st) {
     const fy_flow_config& c = f->cfg;
     const int D = c.dim, C = c.mel, inner = c.heads * c.head_dim, FF = D * c.ff_mult;
     const int M = nseq * Tmax;
+    // FY_PRECISE: every linear takes its activations in fp32 and splits them into bf16 hi + lo on the fly (the weights are
+    // bf16-exact in the tests, so the products carry ~16 mantissa bits into an fp32 accumulation), the attention runs in
+    // fp32, GELU uses the exact tanh: an fp32-class estimator that meets the reference's own bar for swapping the estimator
+    // (rtol 1e-2 / atol 1e-4, cosyvoice/bin/export_onnx.py:109).
+    const bool pr = (flags & FY_PRECISE) != 0;
     GemmEpi e;
     e.bias = f->b_in; e.out = f->h; e.out_bf16 = 0; e.ldc = D;
-    FY_TRY(gemm_bf16(f->a_in, 4 * C, f->w_in, M, D, 4 * C, e, st));
+    if (pr) FY_TRY(gemm_f32a_precise(f->a_in32, 4 * C, f->w_in, M, D, 4 * C, e, st));
+    else FY_TRY(gemm_bf16(f->a_in, 4 * C, f->w_in, M, D, 4 * C, e, st));
     {   // x = conv_pos_embed(x) + x, modules.py:129-144 (causal, grouped, Mish)
         ConvDesc d;
         memset(&d, 0, sizeof(d));
@@ -400,30 +463,40 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
     for (int i = 0; i < c.depth; ++i) {
         const FlowBlockW& k = f->blk[i];
         const float* m = modbase + (size_t)i * 6 * D;       // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + D, m, f->xn, M, D);
+        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + D, m, f->xn, pr ? f->xn32 : nullptr, M, D);
         GemmEpi q;
-        q.bias = k.bqkv; q.out = f->qkv; q.out_bf16 = 1; q.ldc = 3 * inner;
+        q.bias = k.bqkv; q.out = pr ? (void*)f->qkv32 : (void*)f->qkv; q.out_bf16 = pr ? 0 : 1; q.ldc = 3 * inner;
         // x-transformers rotary embedding (head 0 of q and k only, modules.py:368-373) in the projection's epilogue, on the fp32
         // sums before they are rounded to bf16
         q.rope = f->rope; q.rope_T = Tmax; q.rope_half = c.head_dim / 2; q.rope_stride = inner;
-        FY_TRY(gemm_bf16(f->xn, D, k.wqkv, M, 3 * inner, D, q, st));
-        FY_TRY(dit_attention(f->qkv, f->ao, f->seq_len, nseq, Tmax, c.heads, streaming ? c.static_chunk : 0, st));
+        if (pr) {
+            FY_TRY(gemm_f32a_precise(f->xn32, D, k.wqkv, M, 3 * inner, D, q, st));
+            hipLaunchKernelGGL(dit_attention_f32_k, dim3(cdiv(Tmax, 4), c.heads, nseq), dim3(256), (size_t)4 * (64 + Tmax) * sizeof(float), st,
+                               f->qkv32, f->ao32, f->seq_len, Tmax, c.heads, streaming ? c.static_chunk : 0);
+        } else {
+            FY_TRY(gemm_bf16(f->xn, D, k.wqkv, M, 3 * inner, D, q, st));
+            FY_TRY(dit_attention(f->qkv, f->ao, f->seq_len, nseq, Tmax, c.heads, streaming ? c.static_chunk : 0, st));
+        }
         GemmEpi o;
         o.mode = EPI_GATE_RESID; o.bias = k.bo; o.resid = f->h; o.gate = m + 2 * D; o.ldc = D;
-        FY_TRY(gemm_bf16(f->ao, inner, k.wo, M, D, inner, o, st));
-        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + 4 * D, m + 3 * D, f->xn, M, D);
+        if (pr) FY_TRY(gemm_f32a_precise(f->ao32, inner, k.wo, M, D, inner, o, st));
+        else FY_TRY(gemm_bf16(f->ao, inner, k.wo, M, D, inner, o, st));
+        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + 4 * D, m + 3 * D, f->xn, pr ? f->xn32 : nullptr, M, D);
         GemmEpi g;
-        g.bias = k.b1; g.act = ACT_GELU_TANH; g.out = f->ff; g.out_bf16 = 1; g.ldc = FF;
-        FY_TRY(gemm_bf16(f->xn, D, k.w1, M, FF, D, g, st));
+        g.bias = k.b1; g.act = ACT_GELU_TANH; g.out = pr ? (void*)f->ff32 : (void*)f->ff; g.out_bf16 = pr ? 0 : 1; g.ldc = FF;
+        if (pr) FY_TRY(gemm_f32a_precise(f->xn32, D, k.w1, M, FF, D, g, st));
+        else FY_TRY(gemm_bf16(f->xn, D, k.w1, M, FF, D, g, st));
         GemmEpi r;
         r.mode = EPI_GATE_RESID; r.bias = k.b2; r.resid = f->h; r.gate = m + 5 * D; r.ldc = D;
-        FY_TRY(gemm_bf16(f->ff, FF, k.w2, M, D, FF, r, st));
+        if (pr) FY_TRY(gemm_f32a_precise(f->ff32, FF, k.w2, M, D, FF, r, st));
+        else FY_TRY(gemm_bf16(f->ff, FF, k.w2, M, D, FF, r, st));
     }
     const float* fn = f->fin + (size_t)slot * 2 * D;            // (scale, shift), modules.py:261
-    hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, fn, fn + D, f->xn, M, D);
+    hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, fn, fn + D, f->xn, pr ? f->xn32 : nullptr, M, D);
     GemmEpi p;
     p.bias = f->b_out; p.out = f->v; p.out_bf16 = 0; p.ldc = C;
-    FY_TRY(gemm_bf16(f->xn, D, f->w_out, M, C, D, p, st));
+    if (pr) FY_TRY(gemm_f32a_precise(f->xn32, D, f->w_out, M, C, D, p, st));
+    else FY_TRY(gemm_bf16(f->xn, D, f->w_out, M, C, D, p, st));
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -480,8 +553,10 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
     }
     hipLaunchKernelGGL(flow_setup_k, dim3(Tmax, B), dim3(128), 0, st, f->mu_tok, prompt_feat, (long)pfeat_rows * C, rand_noise, noise_ld, d_T,
                        d_pmel, f->mu, f->cond, f->x, Tmax, Nmax, C);
+    if (flags & FY_PRECISE) FY_TRY(ensure_precise(f));
     for (int step = 0; step < c.n_timesteps; ++step) {
-        hipLaunchKernelGGL(dit_assemble_k, dim3(Tmax, 2 * B), dim3(4 * C), 0, st, f->x, f->cond, f->mu, f->spks, d_T, f->a_in, Tmax, C);
+        hipLaunchKernelGGL(dit_assemble_k, dim3(Tmax, 2 * B), dim3(4 * C), 0, st, f->x, f->cond, f->mu, f->spks, d_T, f->a_in,
+                           (flags & FY_PRECISE) ? f->a_in32 : nullptr, Tmax, C);
         FY_TRY(dit_forward(f, 2 * B, Tmax, step, (flags & FY_STREAMING) != 0, flags, st));
         hipLaunchKernelGGL(euler_k, dim3(Tmax, B), dim3(128), 0, st, f->x, f->v, d_T, Tmax, C, f->dt_of_step[step], c.cfg_rate);
     }
@@ -549,11 +624,13 @@ extern "C" int fy_dit_estimator(fy_flow* f, float* x, const float* mask, const f
     FY_TRY(transpose_bcl_to_blc(mu, sm, B2, C, T, (long)C * T, (long)T * C, C, st));
     // a_in rows: sequence s uses its own (x, cond, mu, spks): reuse dit_assemble_k per sequence with cfg = 0
     // by viewing each sequence as "batch b = s" with a stride of 2 sequences
+    if (flags & FY_PRECISE) FY_TRY(ensure_precise(f));
     {
         // pack directly: one launch per sequence keeps the kernel unchanged
         for (int s = 0; s < B2; ++s) {
             hipLaunchKernelGGL(dit_assemble_k, dim3(T, 1), dim3(4 * C), 0, st, sx + (size_t)s * T * C, sc + (size_t)s * T * C,
-                               sm + (size_t)s * T * C, spks + (size_t)s * C, f->seq_len + s, f->a_in + (size_t)s * T * 4 * C, T, C);
+                               sm + (size_t)s * T * C, spks + (size_t)s * C, f->seq_len + s, f->a_in + (size_t)s * T * 4 * C,
+                               (flags & FY_PRECISE) ? f->a_in32 + (size_t)s * T * 4 * C : nullptr, T, C);
         }
     }
     // a_in was written by rows of T (not f->Tmax): run the estimator with Tmax = T; h is overwritten only after a_in is complete

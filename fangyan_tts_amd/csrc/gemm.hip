@@ -83,6 +83,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], bf16_t* gm_sm
             o.x = fmaf(gv.x, v.x, o.x); o.y = fmaf(gv.y, v.y, o.y); o.z = fmaf(gv.z, v.z, o.z); o.w = fmaf(gv.w, v.w, o.w);
             *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + n) = o;
         } else if (EPI == 2) {
+            // fp32 output; the fp32-class mode of the flow decoder also wants the activation and the rotary embedding here,
+            // with the exact tanh (the bf16 path's hardware-exp form is only good to bf16 precision)
+            if (e.act == ACT_GELU_TANH) { v.x = act_gelu_tanh(v.x); v.y = act_gelu_tanh(v.y); v.z = act_gelu_tanh(v.z); v.w = act_gelu_tanh(v.w); }
+            if (e.rope) epi_rope(v, e, m, n);
             *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
         } else {
             if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
@@ -428,7 +432,7 @@ template <bool PRECISE>
 static int gemm_launch(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     if (epi.mode == EPI_GATE_RESID) return gemm_launch2<PRECISE, 3>(A, lda, W, M, N, K, epi, st);
     if (!epi.out_bf16) {
-        FY_CHECK(epi.act == ACT_NONE, FY_ERR_ARG, "gemm: fp32 output has no fused activation");
+        FY_CHECK(epi.act == ACT_NONE || epi.act == ACT_GELU_TANH, FY_ERR_ARG, "gemm: only GELU(tanh) is fused");
         return gemm_launch2<PRECISE, 2>(A, lda, W, M, N, K, epi, st);
     }
     if (epi.act == ACT_GELU_TANH) return gemm_launch2<PRECISE, 1>(A, lda, W, M, N, K, epi, st);
@@ -441,7 +445,7 @@ static int gemm_check(const void* A, int lda, const bf16_t* W, int M, int N, int
     FY_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && (lda * a_elem) % 16 == 0, FY_ERR_ARG, "gemm: operands must be 16-B aligned");
     FY_CHECK(e.ldc >= N && ((e.mode == EPI_STORE && e.out) || (e.mode == EPI_GATE_RESID && e.resid && e.gate)), FY_ERR_ARG, "gemm: bad epilogue");
     FY_CHECK(N % 4 == 0 && e.ldc % 4 == 0, FY_ERR_ARG, "gemm: N and the output pitch must be multiples of 4 (N %d, ldc %d)", N, e.ldc);
-    FY_CHECK(!e.rope || (e.mode == EPI_STORE && e.out_bf16 && e.act == ACT_NONE && e.rope_T >= 1 && e.rope_half >= 2 && e.rope_half % 2 == 0 &&
+    FY_CHECK(!e.rope || (e.mode == EPI_STORE && e.act == ACT_NONE && e.rope_T >= 1 && e.rope_half >= 2 && e.rope_half % 2 == 0 &&
                          e.rope_stride >= 2 * e.rope_half), FY_ERR_ARG, "gemm: bad rotary epilogue");
     return FY_OK;
 }

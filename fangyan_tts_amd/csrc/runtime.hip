@@ -195,3 +195,19 @@ extern "C" int fy_stream_overlap(void* const* streams, int32_t n, float* ratio) 
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
+
+// A stream whose kernels may run only on the compute units set in `mask` (bit i of word i / 32 = CU i), created by the HIP
+// runtime this library is bound to - the one torch uses in the same process (a second runtime loaded by name from Python
+// could be a different copy).
+extern "C" int fy_stream_create_masked(void** out, const uint32_t* mask, int32_t n_words) {
+    FY_CHECK(out && mask && n_words >= 1, FY_ERR_ARG, "fy_stream_create_masked: bad arguments");
+    hipStream_t st = nullptr;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask));
+    *out = (void*)st;
+    return FY_OK;
+}
+
+extern "C" int fy_stream_destroy(void* stream) {
+    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return FY_OK;
+}

@@ -46,6 +46,11 @@ int fy_prof_get(const char* name, double* total_ms, double* work, int64_t* count
  * the concurrent LM / flow streams of the pipelined path (cli/model.py runs the LM in its own thread beside
  * token2wav, cli/model.py:101-129, 339-369); ~3 ms per pair.                                                           */
 int fy_stream_overlap(void* const* streams, int32_t n, float* ratio);
+/* A HIP stream restricted to the compute units whose bits are set in mask (word i / 32, bit i % 32), made by the runtime this
+ * library is bound to; fy_stream_destroy releases it.  Used to keep the flow / vocoder stream off a few CUs so a single LM
+ * stream beside it is not starved (cli/model.py's LM thread beside token2wav).                                            */
+int fy_stream_create_masked(void** out, const uint32_t* mask, int32_t n_words);
+int fy_stream_destroy(void* stream);
 
 /* ---- flags ------------------------------------------------------------------ */
 #define FY_PRECISE 1u /* split-bf16 (hi+lo) activations on the MFMA paths: fp32-class accuracy, 2x MFMA work */
@@ -197,6 +202,19 @@ int fy_llm_decode_mode(const fy_llm* l);
  * Only the first FY_LLM_KEEP_LOGP steps are kept.                                                            */
 #define FY_LLM_KEEP_LOGP 4
 int fy_llm_logp(fy_llm* l, int32_t step, float* dst, void* stream);
+
+/* ================================ frontend: prompt mel ================================
+ * replaces matcha.utils.audio.mel_spectrogram as cosyvoice3.yaml:140-148 configures it (n_fft = win = 1920, hop 480, 80 mels,
+ * fmin 0, fmax sr/2, center=False), third_party/Matcha-TTS/matcha/utils/audio.py:45-82, called by
+ * CosyVoiceFrontEnd._extract_speech_feat on the 24 kHz prompt (cli/frontend.py:119-125).
+ * wav: device fp32 (n_samples) in [-1, 1]; mel: device fp32 (frames, 80), frames = fy_prompt_mel_frames(n_samples)
+ * (= n_samples / 480 when that divides).  The mel filterbank is librosa's Slaney form restated (librosa is not in the
+ * image: that table is unpinned; the STFT is pinned against torch.stft).                                                   */
+typedef struct fy_prompt_mel fy_prompt_mel;
+int fy_prompt_mel_create(fy_prompt_mel** out, int32_t sample_rate, void* stream);
+void fy_prompt_mel_destroy(fy_prompt_mel* p);
+int fy_prompt_mel_frames(int32_t n_samples);
+int fy_prompt_mel_run(fy_prompt_mel* p, const float* wav, int32_t n_samples, float* mel, int32_t frames, void* stream);
 
 #ifdef __cplusplus
 }

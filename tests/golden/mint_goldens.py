@@ -492,12 +492,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="hift,flow,llm,e2e,stream,ras")
     ap.add_argument("--full", action="store_true", help="also mint the full-size (CosyVoice3-0.5B shape) fixtures")
+    ap.add_argument("--sized", action="store_true", help="mint the fixtures at BASELINE.json's configuration sizes (*_sized.npz; minutes of CPU)")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
     torch.manual_seed(0)
     install_stubs()
     only = set(a.only.split(","))
     tiny = ModelCfg.tiny()
+    if a.sized:
+        # SURVEY 8(c) G3 / G5 / G6 at the sizes BASELINE.json's configurations run at: the DiT at T = 512 (the top of
+        # export_onnx.py's sweep) and T = 650 (config 3: 10 s prompt + 3 s), the 10-step mel at config 2's (75 tokens, 5 s
+        # prompt) and config 3's (75, 10 s prompt) shapes, the LM behind a 250-token prompt (prefill of 296 rows), and the whole
+        # tts() for config 1 (instruct: 8 + 14 text ids, 5 s prompt) and config 3 (zero-shot: 30 prompt-text ids, 250 + 250)
+        if "flow" in only:
+            mint_flow("sized", FlowCfg(), [512, 650], [(75, 125), (75, 250)], a.out)
+        if "llm" in only:
+            mint_llm("sized", LlmCfg(), [(14, 30, 250)], a.out, max_steps=40)
+        if "e2e" in only:
+            mint_e2e("sized", ModelCfg(), [(14, 8, 0, 125), (14, 30, 250, 250)], a.out)
+        return
     if "hift" in only:
         mint_hift("tiny", tiny.hift, [12, 30], a.out)
         if a.full:

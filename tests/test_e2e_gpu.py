@@ -2,11 +2,19 @@
 CosyVoice3Model mirror, against the e2e fixtures minted from the reference's own
 CosyVoice3Model.tts and against the oracle; plus batching invariants.
 
-Stated tolerances (bf16 MFMA in flow and HiFT):
+Stated tolerances, each about 3x what is measured (gpurun_out/parity_e2e.json):
   tokens  bit-exact;
-  mel     max |err| <= 8e-2 against the reference fixture (values of scale ~1.5);
-  wav     (a) max |err| <= 1.5e-2 against the oracle vocoder run on the engine's own mel,
-          (b) max |err| <= 2e-2 against the reference fixture on the first 10 frames.
+  default mode (bf16 MFMA operands in flow and HiFT):
+    mel     max |err| <= 4e-2 against the reference fixture (measured 1.0-1.3e-2; values of scale ~1.5);
+    wav     (a) max |err| <= 2.5e-3 against the oracle vocoder run on the engine's own mel (measured 5-9e-4),
+            (b) max |err| <= 2e-2 against the reference fixture on the first 10 frames (measured <= 7.5e-3),
+            (c) log-mel distance to the fp32-class waveform (phase-insensitive) <= 3 dB at the reduced size, <= 6 dB at
+                full size (measured 0.4-1.1 / 2.4-4.6; a random-weight vocoder is that sensitive: uniform +-1e-2 noise on
+                the mel alone moves the oracle's waveform by 2.7 dB);
+  fp32-class mode (FY_PRECISE flow + FY_DIRECT vocoder):
+    mel     max |err| <= 6e-5 against the reference fixture (measured 1.5-1.8e-5);
+    wav     the WHOLE waveform against the reference fixture: <= 6e-5 at the reduced size (measured 2.5e-5), <= 1.5e-3 at
+            full size (measured 1.4-4.9e-4).
 Why the wav is not compared sample-wise over its whole length against the fp32 reference: the
 vocoder's harmonic source integrates f0 over time (phase = 2 pi 480 cumsum(h f0 / 24000),
 hifigan/generator.py:255-258), so a 1e-2 mel difference grows into an O(1) phase difference of
@@ -62,12 +70,12 @@ CASES = [(8, 6, 0, 12), (6, 5, 20, 20)]
 def wav_checks(m, cfg, sd_hift, wav, samples, f, ctag, ri, sn, tag):
     from oracle import hift as ohift
     mel = m.last_mel.cpu()
-    check(mel, f, f"c{ctag}.mel", 5e-2, 8e-2)
+    check(mel, f, f"c{ctag}.mel", 0.0, 4e-2)
     P = ohift.prepare({k: v.cpu().numpy() for k, v in sd_hift.items()})
     ref, _ = ohift.inference(mel, P, cfg.hift, ri, sn[:, :samples])
     e = maxerr(wav[:, :samples], ref)
     note("parity_e2e.json", f"{tag}.wav_vs_oracle_vocoder_on_engine_mel", e)
-    assert e < 1.5e-2
+    assert e < 2.5e-3
     idx = sample_idx(samples)
     early = idx < 4800
     got = wav[0, :samples].numpy()[idx][early]
@@ -88,6 +96,51 @@ def test_tts_against_reference_fixture(tiny):
         out = next(m.tts(**inp))["tts_speech"]          # the reference-shaped generator API
         assert out.shape == (1, samples[0]) and out.device.type == "cpu"
         assert torch.equal(out, wav[:, : samples[0]])
+
+
+def _fp32_class(m, on):
+    from fangyan_tts_amd._lib import FY_DIRECT, FY_PRECISE
+    m.flow_flags, m.hift_flags = (FY_PRECISE, FY_DIRECT) if on else (0, 0)
+
+
+def whole_wav_checks(m, cfg, sd, inp, f, ctag, ri, sn, tag, mel_atol, wav_atol, logmel_db):
+    """(1) fp32-class mode (FY_PRECISE flow + FY_DIRECT vocoder): mel and the WHOLE waveform against the reference fixture
+    (4096 samples strided over the whole length + the sum).  (2) default bf16 mode: the waveform against the fp32-class one by
+    a phase-insensitive measure, the mean |difference| of the log-mel spectra in dB (bench.logmel_distance) - sample-wise the
+    two drift apart once the harmonic source has integrated the ~1e-2 mel difference (header)."""
+    import bench
+    _fp32_class(m, True)
+    try:
+        wav_p, samples, toks = m.tts_batch([inp])
+        mel_p = m.last_mel.cpu()
+    finally:
+        _fp32_class(m, False)
+    assert toks[0].cpu().tolist() == f[f"c{ctag}.tokens"].tolist()
+    S = samples[0]
+    ref_s = f[f"c{ctag}.wav.samples"]
+    got_s = wav_p[0, :S].numpy()[sample_idx(S)]
+    e_w = float(np.abs(got_s - ref_s).max())
+    ref_m = f[f"c{ctag}.mel.samples"]
+    got_m = mel_p.reshape(-1).numpy()[sample_idx(mel_p.numel())]
+    e_m = float(np.abs(got_m - ref_m).max())
+    note("parity_e2e.json", f"{tag}.fp32_class.mel_maxerr_vs_reference", e_m)
+    note("parity_e2e.json", f"{tag}.fp32_class.wav_whole_length_maxerr_vs_reference", e_w)
+    assert e_m < mel_atol, e_m
+    assert e_w < wav_atol, e_w
+    check(wav_p[:, :S], f, f"c{ctag}.wav", 0.0, wav_atol)
+    wav, samples2, _ = m.tts_batch([inp])
+    assert samples2[0] == S
+    d = bench.logmel_distance(wav[:, :S], wav_p[:, :S])
+    note("parity_e2e.json", f"{tag}.bf16_vs_fp32_class.logmel_db", d)
+    assert d < logmel_db, d
+
+
+def test_whole_waveform_against_reference(tiny):
+    m, cfg, sd, ri, sn = tiny
+    f = golden("e2e_tiny.npz")
+    for c in CASES:
+        inp, ctag = e2e_input(cfg, *c)
+        whole_wav_checks(m, cfg, sd, inp, f, ctag, ri, sn, f"tiny.{ctag}", 6e-5, 6e-5, 3.0)
 
 
 def test_batch_equals_solo(tiny):
@@ -113,6 +166,34 @@ def test_full_size_against_reference_fixture():
     wav, samples, toks = m.tts_batch([inp])
     assert toks[0].cpu().tolist() == f[f"c{ctag}.tokens"].tolist()
     wav_checks(m, cfg, sd[2], wav, samples[0], f, ctag, ri, sn, "full")
+    whole_wav_checks(m, cfg, sd, inp, f, ctag, ri, sn, "full", 6e-5, 1.5e-3, 6.0)
+
+
+@pytest.mark.parametrize("case,name", [((14, 8, 0, 125), "config1_instruct"), ((14, 30, 250, 250), "config3_zero_shot")])
+def test_configuration_sizes_against_reference_fixture(case, name):
+    """BASELINE.json configs 1 and 3 at their real sizes - instruct: 8 + 14 text ids behind a 5 s prompt; zero-shot: 30
+    prompt-text ids, 250 prompt speech tokens in the LM (a 296-row prefill) and 10 s of prompt mel (DiT sequence 500 + 2n) -
+    against fixtures minted from the reference's CosyVoice3Model.tts with its own stopping rule: ids exact, mel, waveform."""
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    f = golden("e2e_sized.npz")
+    if f is None:
+        pytest.skip("e2e_sized.npz not minted")
+    cfg = ModelCfg()
+    n_text, n_ptext, p_llm, p_flow = case
+    sd = [synth.state_dict_torch(mm.manifest(), DEV, skip=("lm_head",)) for mm in (cfg.llm, cfg.flow, cfg.hift)]
+    noise = torch.from_numpy(synth.flow_rand_noise(2 * (p_flow + 20 * n_text)))
+    ri = torch.from_numpy(synth.hift_rand_ini())
+    sn = torch.from_numpy(synth.hift_sine_noise(2 * 20 * n_text * 480))
+    m = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, device=DEV, max_batch=1, max_text=64, max_prompt_tokens=250, max_tokens=20 * n_text,
+                        rand_noise=noise, rand_ini=ri, sine_noise=sn)
+    inp, ctag = e2e_input(cfg, *case)
+    wav, samples, toks = m.tts_batch([inp])
+    got, ref = toks[0].cpu().tolist(), f[f"c{ctag}.tokens"].tolist()
+    first_bad = next((i for i, (g, r) in enumerate(zip(got, ref)) if g != r), None)
+    note("parity_e2e.json", f"{name}.tokens", [len(got), len(ref), first_bad])
+    assert got == ref, (len(got), len(ref), first_bad)
+    wav_checks(m, cfg, sd[2], wav, samples[0], f, ctag, ri, sn, name)
+    whole_wav_checks(m, cfg, sd, inp, f, ctag, ri, sn, name, 6e-5, 1.5e-3, 6.0)
 
 
 def test_pipeline_equals_batches(tiny):
@@ -144,6 +225,51 @@ def test_pipeline_two_lm_handles(tiny):
             assert maxerr(w[b, : s[b]], w2[b, : s2[b]]) < 1e-5
 
 
+def test_pipeline_abandoned_then_reused(tiny):
+    """A tts_pipeline generator dropped after its first item stops its producers before the engine handles are released:
+    the next call on the same model is correct (no producer still driving an LM handle)."""
+    m2, _, _, _ = build(ModelCfg.tiny(), 4, 20, n_llm=2)
+    m, cfg, sd, ri, sn = tiny
+    ins = [e2e_input(cfg, *c)[0] for c in CASES]
+    batches = [[ins[0]], [ins[1]], [ins[0], ins[1]], [ins[1]], [ins[0]], [ins[1], ins[0]]]
+    g = m2.tts_pipeline(batches, flow_cu_exclude=0)
+    first = next(g)
+    g.close()                                               # abandon: the finally-path joins the producers
+    ref = m.tts_batch(batches[0])
+    assert first[1] == ref[1] and maxerr(first[0][0, : first[1][0]], ref[0][0, : ref[1][0]]) < 1e-5
+    for b in (batches[2], batches[1]):
+        w, s, t = m2.tts_batch(b)
+        w2, s2, t2 = m.tts_batch(b)
+        assert s == s2 and all(torch.equal(a, c) for a, c in zip(t, t2))
+    # and an error inside a producer surfaces in the consumer, after which the model still works
+    bad = [dict(ins[0], text=torch.full((1, 5), cfg.llm.vocab + 7, dtype=torch.int32))]
+    with pytest.raises(RuntimeError):
+        list(m2.tts_pipeline([bad, batches[0]], flow_cu_exclude=0))
+    w, s, t = m2.tts_batch(batches[0])
+    assert s == ref[1] and all(torch.equal(a, c) for a, c in zip(t, ref[2]))
+
+
+def test_pipeline_equals_batches_under_ras():
+    """The reference's default sampler: a batch's uniforms come from a generator seeded (seed, batch counter), so the pipelined
+    path (several LM handles, threads) draws what a sequence of tts_batch calls draws."""
+    cfg = ModelCfg.tiny()
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    sd = [synth.state_dict_torch(mm.manifest(), DEV, skip=("lm_head",)) for mm in (cfg.llm, cfg.flow, cfg.hift)]
+    kw = dict(device=DEV, max_batch=4, max_text=32, max_prompt_tokens=32, max_tokens=160, sampler="ras", sampler_seed=7)
+    a = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, n_llm=1, **kw)
+    b = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, n_llm=2, **kw)
+    b.rand_noise, b.rand_ini, b.sine_noise = a.rand_noise, a.rand_ini, a.sine_noise
+    ins = [e2e_input(cfg, *c)[0] for c in CASES]
+    batches = [[ins[0]], [ins[1], ins[0]], [ins[1]], [ins[0], ins[1]]]
+    ref = [a.tts_batch(x) for x in batches]
+    got = list(b.tts_pipeline(batches, flow_cu_exclude=0))
+    for (w, s, t), (w2, s2, t2) in zip(got, ref):
+        assert s == s2 and all(torch.equal(x, y) for x, y in zip(t, t2))
+    # different batch counters draw different uniforms: the same batch decoded again does not repeat its tokens exactly
+    again = a.tts_batch(batches[0])
+    assert not (again[1] == ref[0][1] and all(torch.equal(x, y) for x, y in zip(again[2], ref[0][2])))
+
+
 def test_long_utterance_against_oracle():
     """A 24 s utterance after a 10 s prompt (600 forced tokens, 250 prompt tokens: DiT sequence 1700 frames, 576 000
     samples, 893 LM positions) at reduced width against the oracle pipeline: ids exact, mel and waveform within the
@@ -173,12 +299,12 @@ def test_long_utterance_against_oracle():
     mel = m.last_mel.cpu()
     e_mel = maxerr(mel, mel_ref)
     note("parity_e2e.json", "long.mel_maxerr", e_mel)
-    assert e_mel < 8e-2
+    assert e_mel < 4e-2
     PH = ohift.prepare({k: v.cpu().numpy() for k, v in sd[2].items()})
     ref, _ = ohift.inference(mel, PH, cfg.hift, ri, sn[:, : samples[0]])
     e = maxerr(wav[:, : samples[0]], ref)
     note("parity_e2e.json", "long.wav_vs_oracle_vocoder_on_engine_mel", e)
-    assert e < 1.5e-2
+    assert e < 2.5e-3
 
 
 def test_stream_overlap_probe():
@@ -193,7 +319,7 @@ def test_stream_overlap_probe():
     r = np.array(r[:]).reshape(4, 4)
     note("parity_e2e.json", "stream_overlap_ratios", [round(float(v), 2) for v in r.reshape(-1)])
     assert np.allclose(r, r.T) and np.allclose(np.diag(r), 1.0)
-    assert r[0, 3] > 1.6                                   # the same stream twice: its two chains take turns
+    assert r[0, 3] > 1.3                                   # the same stream twice: its two chains take turns (2.0 on an idle box)
     assert (r > 0.7).all() and (r < 4.0).all()
 
 

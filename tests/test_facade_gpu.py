@@ -125,6 +125,83 @@ def test_automodel_drop_in_calls(model_dir):
         list(model.model.tts(text=(torch.zeros(1, 1, dtype=torch.int32) for _ in range(3)), flow_embedding=torch.zeros(1, 192)))
 
 
+def test_facade_against_the_oracle(model_dir):
+    """inference_instruct2 / inference_zero_shot through the facade (checkpoint files on disk -> engines) against the CPU oracle
+    fed the same model_input and the same state dicts: ids exact, mel and waveform within the engines' stated tolerances
+    (tests/test_e2e_gpu.py) - the checkpoint ingestion (generator. prefix, weight-norm folding, shape-inferred sizes) is part
+    of what is compared."""
+    from cosyvoice.cli.cosyvoice import AutoModel
+    from oracle import hift as ohift, pipeline as opipe
+    path, cfg = model_dir
+    fe = FakeFrontEnd(cfg)
+    model = AutoModel(model_dir=path, frontend=fe, max_tokens=160, max_prompt_tokens=32, sampler="greedy")
+    m = model.model
+    sds = [{k: torch.from_numpy(v) for k, v in synth.state_dict(x.manifest()).items()} for x in (cfg.llm, cfg.flow, cfg.hift)]
+    PH = ohift.prepare({k: v.numpy() for k, v in sds[2].items()})
+    noise, ri, sn = m.rand_noise.cpu(), m.rand_ini.cpu(), m.sine_noise.cpu()
+    for call, inp in ((lambda: model.inference_instruct2("你好世界", "用四川话说<|endofprompt|>", "prompt.wav"),
+                       fe.frontend_instruct2("你好世界", "用四川话说<|endofprompt|>", "prompt.wav", 24000, "")),
+                      (lambda: model.inference_zero_shot("你好世界", "提示<|endofprompt|>", "prompt.wav"),
+                       fe.frontend_zero_shot("你好世界", "提示<|endofprompt|>", "prompt.wav", 24000, ""))):
+        wav = list(call())[0]["tts_speech"]
+        ref = opipe.tts(inp, sds[0], sds[1], PH, cfg, noise, ri, sn)
+        assert wav.shape == ref["tts_speech"].shape                      # same token count (ids drive the length)
+        mel = m.last_mel.cpu()
+        assert maxerr(mel, ref["mel"]) < 4e-2
+        ref_wav, _ = ohift.inference(mel, PH, cfg.hift, ri, sn[:, : wav.shape[1]])
+        assert maxerr(wav, ref_wav) < 2.5e-3
+        # fp32-class mode: the whole waveform against the oracle's
+        from fangyan_tts_amd._lib import FY_DIRECT, FY_PRECISE
+        m.flow_flags, m.hift_flags = FY_PRECISE, FY_DIRECT
+        try:
+            wav_p = list(call())[0]["tts_speech"]
+        finally:
+            m.flow_flags, m.hift_flags = 0, 0
+        assert maxerr(wav_p, ref["tts_speech"]) < 1e-4
+
+
+def test_concurrent_tts_calls(model_dir):
+    """Two threads inside tts() on one model object (the reference's contract: runtime/python/grpc/server.py:68-69,
+    cli/model.py:330-333) both get the audio a lone call gets - with one engine set (calls take turns) and with
+    concurrency=2 (two engine sets, both calls run at once)."""
+    import threading
+    from cosyvoice.cli.cosyvoice import AutoModel
+    path, cfg = model_dir
+    fe = FakeFrontEnd(cfg)
+    jobs = [("你好世界", "用四川话说<|endofprompt|>", "prompt.wav"), ("今天天气不错", "用粤语说<|endofprompt|>", "other.wav")]
+    for conc in (1, 2):
+        model = AutoModel(model_dir=path, frontend=fe, max_tokens=160, max_prompt_tokens=32, sampler="greedy", concurrency=conc)
+        alone = [list(model.inference_instruct2(*j))[0]["tts_speech"] for j in jobs]
+        got, errs = [None, None], []
+
+        def work(i):
+            try:
+                for _ in range(3):
+                    got[i] = list(model.inference_instruct2(*jobs[i]))[0]["tts_speech"]
+            except BaseException as e:            # noqa: BLE001
+                errs.append(e)
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        for i in range(2):
+            assert got[i].shape == alone[i].shape and maxerr(got[i], alone[i]) == 0.0, (conc, i)
+
+
+def test_capacity_errors_come_up_front(model_dir):
+    from cosyvoice.cli.cosyvoice import AutoModel
+    path, cfg = model_dir
+    fe = FakeFrontEnd(cfg)
+    model = AutoModel(model_dir=path, frontend=fe, max_tokens=100, max_prompt_tokens=32, sampler="greedy")
+    with pytest.raises(ValueError, match="max_tokens"):         # 7 text ids -> up to 140 tokens > 100
+        list(model.inference_instruct2("你好世界", "用四川话说<|endofprompt|>", "prompt.wav"))
+    model = AutoModel(model_dir=path, frontend=fe, max_tokens=160, max_prompt_tokens=8, sampler="greedy")
+    with pytest.raises(ValueError, match="max_prompt_tokens"):
+        list(model.inference_instruct2("你好世界", "用四川话说<|endofprompt|>", "prompt.wav"))
+
+
 def test_automodel_errors(tmp_path):
     from fangyan_tts_amd.cli.cosyvoice import AutoModel
     with pytest.raises(ValueError):

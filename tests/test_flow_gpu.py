@@ -4,8 +4,9 @@ C ABI against the CPU oracle and the fixtures minted from the reference.
 The estimator runs bf16 MFMA GEMMs with fp32 accumulation on an fp32 residual stream; the
 reference's own acceptance bar for swapping the estimator is rtol 1e-2 / atol 1e-4
 (cosyvoice/bin/export_onnx.py:109, fp32 ORT vs fp32 torch).  With bf16 operands the stated
-tolerance here is: max abs error <= 4e-2 on estimator outputs of unit scale (std ~1) and
-<= 6e-2 on the 10-step mel (std ~1.5), mean abs error <= 6e-3 / 1e-2.
+tolerance here is about 3x what is measured (gpurun_out/parity_flow.json): max abs error <= 4e-2 on estimator
+outputs of unit scale (measured 1.2-1.6e-2), <= 5e-2 on the 10-step mel (measured 1.1-1.7e-2), mean abs error <= 6e-3 / 1e-2
+(2.5e-3).  With FY_PRECISE (fp32-class) the estimator meets the reference's bar itself: measured 2e-5.
 """
 import numpy as np
 import pytest
@@ -58,13 +59,78 @@ def test_estimator(which, T, tiny, full):
     assert e < 4e-2 and m < 6e-3, (e, m)
     f = golden(f"flow_{which}.npz")
     if f is not None:
-        check(y.cpu(), f, f"est{T}", 2e-2, 4e-2)
+        check(y.cpu(), f, f"est{T}", 0.0, 4e-2)
     ys = eng.estimator(d(x), d(mask), d(mu), d(t), d(spks), d(cond), streaming=True)
     e = maxerr(ys, ref_s)
     note("parity_flow.json", f"est.{which}.{T}.stream.max", e)
     assert e < 4e-2
     if T > cfg.static_chunk:
         assert maxerr(ref, ref_s) > 1e-2        # the chunk mask really changes the answer
+
+
+@pytest.mark.parametrize("which,T", [("tiny", 16), ("tiny", 150), ("full", 16), ("full", 150)])
+def test_estimator_precise_meets_the_reference_bar(which, T, tiny, full):
+    """FY_PRECISE (fp32 activations split into bf16 hi + lo for every linear, fp32 attention, exact tanh): the estimator meets
+    the reference's OWN acceptance bar for replacing it - assert_allclose(rtol=1e-2, atol=1e-4), cosyvoice/bin/export_onnx.py:109 -
+    against the oracle and against the fixture minted from the reference, plain and with the streaming chunk mask."""
+    from fangyan_tts_amd._lib import FY_PRECISE
+    eng, P, o = tiny if which == "tiny" else full
+    x, mu, cond, spks, t = dit_inputs(T)
+    mask = torch.ones(2, 1, T)
+    d = lambda z: z.to(DEV)
+    for streaming in (False, True):
+        with torch.no_grad():
+            ref = o.dit_forward(x, mask, mu, t, spks, cond, P, eng.cfg, streaming=streaming)
+        y = eng.estimator(d(x), d(mask), d(mu), d(t), d(spks), d(cond), streaming=streaming, flags=FY_PRECISE).cpu()
+        e = maxerr(y, ref)
+        note("parity_flow.json", f"est_precise.{which}.{T}.{'stream' if streaming else 'plain'}.max", e)
+        np.testing.assert_allclose(y.numpy(), ref.numpy(), rtol=1e-2, atol=1e-4)
+        assert e < 7e-5, e                                    # measured 1.3-2.3e-5
+    f = golden(f"flow_{which}.npz")
+    if f is not None:
+        y = eng.estimator(d(x), d(mask), d(mu), d(t), d(spks), d(cond), flags=FY_PRECISE).cpu()
+        check(y, f, f"est{T}", 1e-2, 1e-4)
+
+
+@pytest.mark.parametrize("T", [512, 650])
+def test_estimator_at_configuration_sizes(T):
+    """CosyVoice3-0.5B shapes at T = 512 (the top of export_onnx.py:95-110's sweep) and T = 650 (BASELINE config 3: a 10 s
+    prompt + 3 s) against fixtures minted from the reference's DiT: bf16 default within its tolerance, FY_PRECISE within the
+    reference's bar."""
+    from fangyan_tts_amd._lib import FY_PRECISE
+    f = golden("flow_sized.npz")
+    if f is None:
+        pytest.skip("flow_sized.npz not minted")
+    eng, _, _ = make(FlowCfg(), max_batch=1, max_frames=T)
+    x, mu, cond, spks, t = dit_inputs(T)
+    mask = torch.ones(2, 1, T)
+    d = lambda z: z.to(DEV)
+    y = eng.estimator(d(x), d(mask), d(mu), d(t), d(spks), d(cond)).cpu()
+    check(y, f, f"est{T}", 0.0, 5e-2)                           # measured 1.5-1.6e-2 at these lengths
+    ys = eng.estimator(d(x), d(mask), d(mu), d(t), d(spks), d(cond), streaming=True).cpu()
+    check(ys, f, f"est{T}.stream", 0.0, 5e-2)
+    yp = eng.estimator(d(x), d(mask), d(mu), d(t), d(spks), d(cond), flags=FY_PRECISE).cpu()
+    check(yp, f, f"est{T}", 1e-2, 1e-4)
+    note("parity_flow.json", f"est_sized.{T}.bf16_vs_precise.max", maxerr(y, yp))
+
+
+@pytest.mark.parametrize("n,p", [(75, 125), (75, 250)])
+def test_cfm_at_configuration_sizes(n, p):
+    """The 10-step mel at BASELINE config 2's (75 tokens behind a 5 s prompt, T = 400) and config 3's (10 s prompt, T = 650)
+    shapes against the reference's CausalMaskedDiffWithDiT.inference fixture."""
+    from fangyan_tts_amd._lib import FY_PRECISE
+    f = golden("flow_sized.npz")
+    if f is None:
+        pytest.skip("flow_sized.npz not minted")
+    cfg = FlowCfg()
+    eng, _, _ = make(cfg, max_batch=1, max_frames=2 * (n + p))
+    token, ptoken, pfeat, emb = cfm_case(cfg, n, p)
+    z = torch.from_numpy(synth.flow_rand_noise(2 * (n + p)))
+    mel = eng.inference(token, [n], ptoken, [p], pfeat, [2 * p], emb, z)
+    check(mel.cpu(), f, f"cfm{n}_{p}", 0.0, 5e-2)
+    melp = eng.inference(token, [n], ptoken, [p], pfeat, [2 * p], emb, z, flags=FY_PRECISE)
+    check(melp.cpu(), f, f"cfm{n}_{p}", 0.0, 1e-4)
+    note("parity_flow.json", f"cfm_sized.{n}_{p}.bf16_vs_precise.max", maxerr(mel, melp))
 
 
 def test_estimator_masked_rows(tiny):
@@ -105,10 +171,10 @@ def test_cfm_against_reference(which, n, p, tiny, full):
     e, m = maxerr(mel, ref), meanerr(mel, ref)
     note("parity_flow.json", f"cfm.{which}.{n}_{p}.max", e)
     note("parity_flow.json", f"cfm.{which}.{n}_{p}.mean", m)
-    assert e < 6e-2 and m < 1e-2, (e, m)
+    assert e < 5e-2 and m < 1e-2, (e, m)
     f = golden(f"flow_{which}.npz")
     if f is not None:
-        check(mel.cpu(), f, f"cfm{n}_{p}", 3e-2, 6e-2)
+        check(mel.cpu(), f, f"cfm{n}_{p}", 0.0, 5e-2)
 
 
 def test_ragged_batch_equals_solo(tiny):

@@ -71,7 +71,7 @@ def test_f0_and_source(env):
 
 
 @pytest.mark.parametrize("mode,flags,tol_tap,tol_wav", [
-    ("direct", 2, 2e-4, 5e-5), ("precise", 1, 2e-3, 5e-4), ("bf16", 0, 3e-2, 1e-2)])
+    ("direct", 2, 2e-5, 2e-6), ("precise", 1, 4e-5, 2e-6), ("bf16", 0, 4.5e-2, 1.5e-3)])
 def test_decode_against_oracle(env, mode, flags, tol_tap, tol_wav):
     o, eng, cfg = env["o"], env["eng"], env["cfg"]
     Fr = 30
@@ -103,7 +103,7 @@ def test_golden_reference_wav(env):
     check(wav.cpu(), f, "F30.wav", 1e-3, 2e-3)
     np.testing.assert_allclose(wav.cpu().numpy(), f["F30.wav_full"], atol=2e-3)
     wav2, _ = eng.inference(mel_of(30).to(env["dev"]), env["ri_d"], env["sn_d"], flags=0)
-    np.testing.assert_allclose(wav2.cpu().numpy(), f["F30.wav_full"], atol=1.5e-2)
+    np.testing.assert_allclose(wav2.cpu().numpy(), f["F30.wav_full"], atol=1.5e-3)       # measured 4.6e-4
     note("golden.wav_bf16_maxerr", float(np.abs(wav2.cpu().numpy() - f["F30.wav_full"]).max()))
 
 
@@ -115,7 +115,7 @@ def test_resblock(env, index):
     with torch.no_grad():
         ref = o.resblock(x, env["P"], f"resblocks.{index}", cfg.rb_d)
     f = np.load(os.path.join(G, "hift_full.npz")) if os.path.exists(os.path.join(G, "hift_full.npz")) else None
-    for mode, flags, tol in (("direct", 2, 2e-4), ("precise", 1, 2e-3), ("bf16", 0, 4e-2)):
+    for mode, flags, tol in (("direct", 2, 1.5e-5), ("precise", 1, 3e-5), ("bf16", 0, 1.6e-2)):      # measured 4e-6 / 9e-6 / 5.3e-3
         y = eng.resblock(index, x.to(env["dev"]), flags)
         e = maxerr(y, ref)
         note(f"resblock{index}.{mode}", e)
@@ -148,7 +148,7 @@ def test_full_inference_against_oracle(env):
     mel = mel_of(30)[:, :, :Fr].contiguous()
     with torch.no_grad():
         ref, _ = o.inference(mel, env["P"], cfg, env["ri"], env["sn"][:, : Fr * 480])
-    for mode, flags, tol in (("direct", 2, 2e-3), ("bf16", 0, 1.5e-2)):
+    for mode, flags, tol in (("direct", 2, 2.5e-5), ("bf16", 0, 2.5e-3)):                # measured 7e-6 / 7.4e-4
         wav, _ = eng.inference(mel.to(env["dev"]), env["ri_d"], env["sn_d"], flags=flags)
         e = maxerr(wav, ref)
         note(f"inference.{mode}.wav", e)

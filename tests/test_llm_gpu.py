@@ -92,6 +92,21 @@ def test_full_tokens_bit_exact(full):
     run_cases(full, f, [(12, 8, 0), (14, 10, 40)], 60, "full")
 
 
+def test_full_size_behind_a_250_token_prompt(_full250, request):
+    """BASELINE config 3's LM shape (zero-shot: 30 prompt-text ids + 14 text ids + 250 prompt speech tokens = a 296-row prefill)
+    against the fixture minted from the reference's CosyVoice3LM.inference: ids exact, first log-probabilities, both paths."""
+    f = golden("llm_sized.npz")
+    if f is None:
+        pytest.skip("llm_sized.npz not minted")
+    for persistent in (True, False):
+        run_cases(_mode(_full250, persistent), f, [(14, 30, 250)], 40, f"sized.{'persistent' if persistent else 'per-op'}")
+
+
+@pytest.fixture(scope="module")
+def _full250():
+    return make(LlmCfg(), max_batch=1, max_ctx=2 + 44 + 250 + 64)
+
+
 def test_forced_length_and_min_len(tiny):
     """min_len = max_len = n (the benchmark's forced length) emits exactly n real speech tokens."""
     cfg = tiny.cfg

@@ -117,6 +117,7 @@ def test_stft_istft_roundtrip_and_torch():
 @pytest.mark.parametrize("tag,cfg,Ts,cases", [
     ("tiny", FlowCfg.tiny(), (16, 150), ((20, 10), (24, 0))),
     ("full", FlowCfg(), (16,), ()),
+    ("sized", FlowCfg(), (650,), ()),          # BASELINE config 3's DiT sequence (10 s prompt + 3 s); T = 512 and the 10-step mels are GPU-side only (CPU minutes)
 ])
 def test_flow_against_reference(tag, cfg, Ts, cases):
     f = fx(f"flow_{tag}.npz")
@@ -156,10 +157,12 @@ def test_euler_schedule():
 @pytest.mark.parametrize("tag,cfg,cases,cap", [
     ("tiny", LlmCfg.tiny(), ((12, 8, 0), (10, 6, 30)), None),
     ("full", LlmCfg(), ((12, 8, 0),), 12),
+    ("sized", LlmCfg(), ((14, 30, 250),), 6),    # behind a 250-token prompt (296-row prefill): BASELINE config 3's LM shape
 ])
 def test_llm_tokens_bit_exact(tag, cfg, cases, cap):
     f = fx(f"llm_{tag}.npz")
-    if tag == "full":
+    big = tag in ("full", "sized")
+    if big:
         # only the rows the case gathers: the 151 936-row table is 136 M values
         man = {k: v for k, v in cfg.manifest().items() if "embed_tokens" not in k and "lm_head" not in k}
         P = ollm.prepare(synth.state_dict(man))
@@ -168,7 +171,7 @@ def test_llm_tokens_bit_exact(tag, cfg, cases, cap):
     for c in cases:
         ctag = "%d_%d_%d" % c
         text, ptext, ptok = llm_case(cfg, *c, ctag)
-        if tag == "full":
+        if big:
             ids = torch.cat([ptext, text], dim=1)[0].tolist()
             uniq = sorted(set(ids))
             rows = synth.tensor("llm.model.model.embed_tokens.weight", (cfg.vocab, cfg.hidden), rows=uniq)

@@ -33,7 +33,7 @@ def test_hift_chunk(tag):
     mel = torch.from_numpy(synth.uniform(f"in.hift.mel.{Fr}", (1, 80, Fr), 0.0, 1.0)).to(DEV)
     ri = torch.from_numpy(synth.hift_rand_ini()).to(DEV)
     sn = torch.from_numpy(synth.hift_sine_noise(40 * 480)).to(DEV)
-    for mode, flags, tol in (("direct", 2, 2e-3), ("bf16", 0, 1.5e-2)):
+    for mode, flags, tol in (("direct", 2, 3e-5), ("bf16", 0, 2e-3)):                     # measured 1e-5 / 6e-4
         wav, src = eng.inference(mel, ri, sn, flags=flags, want_source=True, finalize=False)
         n = (Fr - 8) * 480
         e = float(np.abs(wav[0, :n].cpu().numpy() - f[f"hift.F{Fr}.wav_full"][0]).max())
@@ -68,7 +68,7 @@ def test_flow_chunk(tag, n, p_tok):
     mel = eng.inference(token, [n], ptoken, [p_tok], pfeat, [2 * p_tok], emb, noise, streaming=True, finalize=False)
     valid = 2 * (n - cfg.pre_lookahead)
     assert float(mel[:, :, valid:].abs().max()) == 0.0
-    check(mel[:, :, :valid].cpu(), f, f"flow.{n}_{p_tok}", 5e-2, 6e-2)
+    check(mel[:, :, :valid].cpu(), f, f"flow.{n}_{p_tok}", 0.0, 5e-2)
 
 
 @pytest.mark.parametrize("tag,case", [("tiny", (40, 6, 0, 12)), ("full", (8, 8, 0, 25))])
@@ -120,7 +120,7 @@ def test_tts_stream_against_reference(tag, case):
         worst = max(worst, maxerr(c, ref[:, off:end]))
         off = end
     note("parity_stream.json", f"tts_stream.{tag}.chunk_wav_vs_oracle_vocoder_on_engine_mel", worst)
-    assert worst < 1.5e-2
+    assert worst < 2.5e-3                                   # measured 8e-4
     # and the first 10 frames of the stream against the reference fixture itself
     from _digest import sample_idx
     si = sample_idx(first[0])
