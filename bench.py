@@ -80,7 +80,9 @@ def cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inp, noise, ri, sn, timed=None):
         # flow decoder at this size (1.3e-2, gpurun_out/parity_flow.json); wav against the oracle vocoder run on the engine's
         # own mel (sample-wise comparison with an fp32-mel waveform is only meaningful for the first frames: the harmonic
         # source integrates f0, tests/test_e2e_gpu.py) within 3x the measured 8e-4, and the log-mel distance between the two
-        # complete waveforms (phase-insensitive) for the whole utterance
+        # complete waveforms (phase-insensitive) for the whole utterance: 3 dB = 3x the measured 1.0 (a random-weight
+        # vocoder turns uniform +-1e-2 noise on the mel into 2.7 dB; the fp32-class mode matches the reference's waveform
+        # sample by sample over its whole length, tests/test_e2e_gpu.py)
         ids = timed["toks"][0].reshape(-1).tolist()
         ref_ids = out["tokens"].reshape(-1).tolist()
         n = len(ref_ids)
@@ -94,8 +96,8 @@ def cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inp, noise, ri, sn, timed=None):
         checked = {"what": "utterance 0 of the last timed step vs the CPU oracle", "ids_equal": ids == ref_ids, "n_ids": n,
                    "mel_max_abs_err": round(e_mel, 5), "mel_tol": 4e-2,
                    "wav_vs_oracle_vocoder_on_engine_mel": round(e_wav, 6), "wav_tol": 2.5e-3,
-                   "logmel_db_vs_oracle_wav": round(e_lm, 3), "logmel_db_tol": 1.0,
-                   "ok": bool(ids == ref_ids and e_mel <= 4e-2 and e_wav <= 2.5e-3 and e_lm <= 1.0)}
+                   "logmel_db_vs_oracle_wav": round(e_lm, 3), "logmel_db_tol": 3.0,
+                   "ok": bool(ids == ref_ids and e_mel <= 4e-2 and e_wav <= 2.5e-3 and e_lm <= 3.0)}
     return base, checked
 
 
@@ -137,6 +139,44 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
+def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, steps=3):
+    """BASELINE.json configs[2] as a secondary object: zero-shot with a 10 s prompt (30 prompt-text ids, 250 prompt speech
+    tokens in the LM = a ~296-row prefill per sequence, 500 prompt mel frames: DiT sequence 650), batch 4, 75 forced tokens,
+    steps one after the other on one stream."""
+    import numpy as np
+    from fangyan_tts_amd import synth
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    B, P = 4, 250
+    noise = torch.from_numpy(synth.flow_rand_noise(2 * (P + N_TOK))).to(dev)
+    ri = torch.from_numpy(synth.hift_rand_ini()).to(dev)
+    sn = torch.from_numpy(synth.hift_sine_noise(2 * N_TOK * 480)).to(dev)
+    m = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=B, max_text=64, max_prompt_tokens=P, max_tokens=N_TOK,
+                        rand_noise=noise, rand_ini=ri, sine_noise=sn)
+    hi = min(cfg.llm.vocab, 151643)
+    inputs = []
+    for b in range(B):
+        tag = f"bench.zs.u{b}"
+        ptok = torch.from_numpy(synth.randint(tag + ".ptok", (1, P), 0, cfg.flow.vocab))
+        inputs.append({"text": torch.from_numpy(synth.randint(tag + ".text", (1, 14), 0, hi)),
+                       "prompt_text": torch.from_numpy(synth.randint(tag + ".ptext", (1, 30), 0, hi)),
+                       "llm_prompt_speech_token": ptok, "flow_prompt_speech_token": ptok,
+                       "prompt_speech_feat": torch.from_numpy(np.clip(synth.normal(tag + ".pfeat", (1, 2 * P, 80), -5.0, 2.0), -11.5, 2.0)),
+                       "flow_embedding": torch.from_numpy(synth.normal(tag + ".spk", (1, 192)))})
+    forced = [N_TOK] * B
+    m.tts_batch(inputs, min_len=forced, max_len=forced)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wav, samples, _ = m.tts_batch(inputs, min_len=forced, max_len=forced)          # wavs end on the host
+    dt = (time.perf_counter() - t0) / steps
+    audio = sum(samples) / 24000.0
+    out = {"workload": "CosyVoice3-0.5B zero-shot, batch 4, 10 s prompt (250 LM prompt tokens, DiT sequence 650), 75 forced tokens each, unpipelined",
+           "ms": round(1e3 * dt, 2), "audio_s_per_s": round(audio / dt, 2), "steps": steps, "lm_decode": "persistent" if m.llm.persistent else "per-op"}
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -147,6 +187,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (zero-shot batch 4, HiFT-only config 5)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
     ap.add_argument("--llm-streams", type=int, default=3, help="LM handles decoding different steps' batches concurrently")
     ap.add_argument("--lm-isolate", action="store_true", help="LM streams run ONLY on the CUs the flow stream is kept off")
@@ -328,6 +369,42 @@ def main():
                                          "GBps": round(step_bytes / (lm_ms / N_TOK * 1e-3) / 1e9, 1),
                                          "note": "un-instrumented LM call alone (prefill of ~25 rows per sequence included); bound by 122 dependent launches per token, not by bandwidth"}}
 
+    # The same decode as ONE persistent launch per token step (llm_decode.hip; what a single LM stream uses - tts, tts_batch,
+    # stream=True; the pipelined steps above keep the per-operation launches because three LM streams interleave with the flow
+    # decoder, which a 152-CU persistent grid cannot): HIP events around every launch of a generation run alone.
+    roofline_lm_p = None
+    if True:
+        eng = model.llms[0]
+        eng.set_decode_mode(True)
+        if eng.persistent:
+            eng.generate(text, ptext, [[] for _ in inputs], min_len=forced, max_len=forced)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            eng.generate(text, ptext, [[] for _ in inputs], min_len=forced, max_len=forced)
+            torch.cuda.synchronize()
+            lm_p_ms = 1e3 * (time.perf_counter() - t3)
+            L.fy_prof_reset()
+            L.fy_prof_only(b"llm_decode")
+            L.fy_prof_enable(1)
+            eng.generate(text, ptext, [[] for _ in inputs], min_len=forced, max_len=forced)
+            torch.cuda.synchronize()
+            L.fy_prof_enable(0)
+            L.fy_prof_only(None)
+            ms_p, bytes_p, n_p = _lib.prof_get("llm_decode")
+            L.fy_prof_reset()
+            gb = bytes_p / (ms_p * 1e-3) / 1e9 if ms_p > 0 else 0.0
+            pmc_p, tr_p = os.path.join(ROOT, "profiles", "r02_llm_decode_pmc.json"), None
+            if os.path.exists(pmc_p):
+                tr_p = json.load(open(pmc_p)).get("traffic_bytes_per_launch")
+            roofline_lm_p = {"bound": "hbm", "kernel": "llm_decode_k: one persistent launch per token step (24 layers + llm_decoder, 152 workgroups, "
+                             "weights register-resident a layer ahead, 121 grid-wide hand-offs)", "achieved": round(gb, 1), "peak": PEAK_HBM_GBPS,
+                             "unit": "GB/s", "frac": round(gb / PEAK_HBM_GBPS, 4), "traffic": tr_p,
+                             "traffic_unit": "bytes per launch (rocprofv3 PMC over this process, profiles/r02_llm_decode_pmc.json)",
+                             "launches": n_p, "avg_launch_us": round(1e3 * ms_p / max(n_p, 1), 1), "algorithmic_bytes_per_launch": int(bytes_p / max(n_p, 1)),
+                             "generate_ms_batch8_75_tokens": round(lm_p_ms, 2),
+                             "measured_over": "HIP events on the launch stream around every launch of one 75-token generation at batch 8, run alone"}
+        eng.set_decode_mode(len(model.llms) == 1)
+
     out = {
         "metric": "synthesised audio sec/sec (RTF^-1) CosyVoice3-0.5B instruct, batch 8",
         "value": round(value, 3), "unit": "audio_s/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -339,8 +416,19 @@ def main():
                    "steps_pipelined": not a.no_pipeline, "llm_streams": 1 if a.no_pipeline else a.llm_streams, "lm_group": 1 if a.no_pipeline else a.lm_group, "flow_cu_exclude": a.flow_cu_exclude, "batch_latency_ms_unpipelined": round(latency_ms, 1),
                    "weights": "random-init, CosyVoice3-0.5B shapes (859 M params)"},
         "roofline": roofline_lm,
+        "roofline_lm_persistent": roofline_lm_p,
         "roofline_dit_linears": roofline,
     }
+    if rank == 0 and world == 1 and not a.no_extras:
+        # behind the timed region: BASELINE.json configs[2] and configs[4] as secondary objects of the same record
+        log("zero-shot batch 4 (config 3)")
+        out["zero_shot_b4"] = bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev)
+        log("HiFT-only 32 x 10 000 frames (config 5)")
+        del model
+        torch.cuda.empty_cache()
+        import bench_hift
+        h5 = bench_hift.run(steps=2, warmup=1)
+        out["hift_cfg5"] = {"workload": h5["config"]["workload"], "ms": h5["ms_per_step"], "audio_s_per_s": h5["value"], "roofline": h5["roofline"]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("timing the CPU oracle on one utterance")
         out["cpu_baseline"], out["checked"] = cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inputs[0], noise, ri, sn, timed)

@@ -29,6 +29,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--flags", type=int, default=0)
     a = ap.parse_args()
+    print(json.dumps(run(a.batch, a.frames, a.steps, a.warmup, a.flags)))
+
+
+def run(batch=32, frames=10000, steps=3, warmup=1, flags=0):
+    """BASELINE.json configs[4] as a function (bench.py reports it as "hift_cfg5")."""
+    import types
+    a = types.SimpleNamespace(batch=batch, frames=frames, steps=steps, warmup=warmup, flags=flags)
     from fangyan_tts_amd import _lib, synth
     from fangyan_tts_amd.hift import HiftEngine
     from fangyan_tts_amd.spec import HiftCfg
@@ -63,14 +70,17 @@ def main():
     if os.path.exists(pmc) and a.flags == 0:
         traffic = int(json.load(open(pmc))["traffic_bytes_per_frame"] * frames)
     bw = frames * BYTES_PER_FRAME / dt
-    print(json.dumps({
+    del eng, mel, sn, wav
+    torch.cuda.empty_cache()
+    return ({
         "metric": "HiFT vocoder audio sec/sec", "value": round(audio / dt, 1), "unit": "audio_s/s", "ms_per_step": round(1e3 * dt, 2),
         "config": {"workload": f"HiFT-only, random mel, batch {a.batch} x {a.frames} frames", "flags": a.flags},
         "roofline": {"bound": "hbm", "achieved": round(bw / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(bw / HBM_PEAK, 4),
                      "traffic": traffic, "traffic_unit": "bytes per step (L2-miss bytes per frame from profiles/r01_hift_pmc.json x frames)",
+                     "frac_on_counter_bytes": round(traffic / dt / HBM_PEAK, 4) if traffic else None,
                      "algorithmic_bytes": int(frames * BYTES_PER_FRAME), "algorithmic_tflops": round(frames * FLOP_PER_FRAME / dt / 1e12, 1),
                      "conv_mfma_ms": round(ms, 2), "conv_mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1) if ms else None,
-                     "conv_mfma_launches": n}}))
+                     "conv_mfma_launches": n}})
 
 
 if __name__ == "__main__":

@@ -112,10 +112,11 @@ extern "C" void fy_prompt_mel_destroy(fy_prompt_mel* p) { delete p; }
 extern "C" int fy_prompt_mel_frames(int32_t n_samples) { return n_samples < PM_PAD + 1 ? 0 : (n_samples + 2 * PM_PAD - PM_NFFT) / PM_HOP + 1; }
 
 extern "C" int fy_prompt_mel_run(fy_prompt_mel* p, const float* wav, int32_t n_samples, float* mel, int32_t frames, void* stream) {
-    FY_CHECK(p && wav && mel, FY_ERR_ARG, "fy_prompt_mel_run: null argument");
+    FY_CHECK(p && wav, FY_ERR_ARG, "fy_prompt_mel_run: null argument");
     FY_CHECK(n_samples > PM_PAD, FY_ERR_ARG, "fy_prompt_mel_run: %d samples are fewer than the reflect padding needs (%d)", n_samples, PM_PAD + 1);
     FY_CHECK(frames == fy_prompt_mel_frames(n_samples), FY_ERR_ARG, "fy_prompt_mel_run: %d samples give %d frames, not %d", n_samples,
              fy_prompt_mel_frames(n_samples), frames);
+    FY_CHECK(mel, FY_ERR_ARG, "fy_prompt_mel_run: null argument");
     hipLaunchKernelGGL(prompt_mel_k, dim3(frames), dim3(256), 0, (hipStream_t)stream, wav, n_samples, p->window, p->tw, p->fb, mel);
     HIP_TRY(hipGetLastError());
     return FY_OK;

@@ -952,6 +952,9 @@ int decode_step(DecodePlan* p, int B, float* h, const int* st_block, const float
     a.hres = h; a.img_h = p->img_h; a.img_ao = p->img_ao; a.ssq_u = p->ssq_u; a.ssq_o = p->ssq_o; a.qkv = p->qkv; a.part = p->part;
     a.logits = logits; a.st = st_block; a.inv_freq = inv_freq; a.flags = p->flags; a.epoch0 = p->epoch; a.status = p->status; a.stamps = p->stamps;
     p->epoch += 1u + 5u * (unsigned)s.layers;               // hand-offs per launch: P0 + five per layer
+    // bench.py's roofline leg: algorithmic bytes of a token step = every bf16 weight once (the launch streams nothing twice)
+    const double wbytes = 2.0 * ((double)s.layers * ((double)s.qkv() * s.H + (double)s.H * s.H + 3.0 * s.I * s.H) + (double)s.NS * s.H);
+    ProfScope prof("llm_decode", wbytes, stream);
     std::lock_guard<std::mutex> lk(g_chain_mu);
     if (!g_chain_ev) HIP_TRY(hipEventCreateWithFlags(&g_chain_ev, hipEventDisableTiming));
     else HIP_TRY(hipStreamWaitEvent(stream, g_chain_ev, 0));

@@ -61,14 +61,15 @@ def test_facade_with_the_real_frontend_class(tmp_path):
     wav = prompt(1.0, seed=5)
     spk = torch.from_numpy(synth.normal("fe.spk.real", (1, 192)))
     stok = lambda s16: [int(v) for v in synth.randint("fe.stok.real", (1, 30), 0, 6561)[0]]       # 30 tokens for 1 s: cut to 25 = 50 frames / 2
-    model = AutoModel(model_dir=str(tmp_path), tokenizer=Tok(), speech_tokenizer=stok, spk_embedder=lambda s16: spk, max_tokens=160,
+    model = AutoModel(model_dir=str(tmp_path), tokenizer=Tok(), speech_tokenizer=stok, spk_embedder=lambda s16: spk, max_tokens=260,
                       max_prompt_tokens=64, sampler="greedy")
     outs = list(model.inference_instruct2("你好世界", "用四川话说<|endofprompt|>", (wav[0].numpy(), 24000)))
     assert len(outs) == 1 and outs[0]["tts_speech"].shape[1] % 480 == 0
     # the same model_input by hand, the mel from the oracle
     mel = ofe.mel_spectrogram(wav)[0].t().unsqueeze(0)[:, :50]
     tok = Tok()
-    inp = {"text": torch.tensor([tok.encode("你好世界")], dtype=torch.int32), "prompt_text": torch.tensor([tok.encode("用四川话说<|endofprompt|>")], dtype=torch.int32),
+    # text_normalize closes the sentence (split_paragraph appends the stop mark): the LM sees "你好世界。"
+    inp = {"text": torch.tensor([tok.encode("你好世界。")], dtype=torch.int32), "prompt_text": torch.tensor([tok.encode("用四川话说<|endofprompt|>")], dtype=torch.int32),
            "flow_prompt_speech_token": torch.tensor([stok(None)[:25]], dtype=torch.int32), "prompt_speech_feat": mel, "flow_embedding": spk}
     w2, s2, _ = model.model.tts_batch([inp])
     assert w2[:, : s2[0]].shape == outs[0]["tts_speech"].shape
