@@ -32,6 +32,10 @@ int gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, co
 // A: fp32 [M][lda], split into bf16 hi + lo on the fly (fp32-class accuracy when W is bf16-exact)
 int gemm_f32a_precise(const float* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st);
 
+// A: fp32 [M][lda], split EXACTLY into bf16 hi + mid + lo (3 MFMAs per fragment): with bf16-exact W every product is exact and
+// the accumulation is fp32 - the LM prefill over many rows (same fidelity as gemv_bf16w, whose 8-row form re-streams the weights)
+int gemm_f32a_exact(const float* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st);
+
 // fp32 [n] -> bf16 [n]
 int cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);
 

@@ -24,6 +24,26 @@ __device__ __forceinline__ void split8(const float4& a, const float4& b, uint4& 
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+// the exact three-way split x = hi + mid + lo (3 x 8 mantissa bits; hardware round-to-nearest-even converts)
+__device__ __forceinline__ void split8_3(const float4& a, const float4& b, uint4& hi, uint4& mid, uint4& lo) {
+    const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t h[8], m[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 hb = (__bf16)f[i];
+        const float r1 = f[i] - (float)hb;
+        const __bf16 mb = (__bf16)r1;
+        const float r2 = r1 - (float)mb;
+        const __bf16 lb = (__bf16)r2;
+        h[i] = __builtin_bit_cast(unsigned short, hb);
+        m[i] = __builtin_bit_cast(unsigned short, mb);
+        l[i] = __builtin_bit_cast(unsigned short, lb);
+    }
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    mid = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
 // x-transformers apply_rotary_pos_emb on four consecutive output columns starting at n (two interleaved pairs)
 __device__ __forceinline__ void epi_rope(float4& v, const GemmEpi& e, int m, int n) {
     int nn = n >= e.rope_stride ? n - e.rope_stride : n;
@@ -103,11 +123,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], bf16_t* gm_sm
 // v_mfma_f32_32x32x16_bf16; BK = 64 with two LDS buffers: the global loads of tile t+1 are issued before
 // the 16 MFMAs of tile t and land in the other buffer after them - one barrier per K step.
 // EPI: 0 store bf16, 1 store bf16 after GELU(tanh), 2 store fp32, 3 gated residual (resid += gate * (acc + bias))
-template <bool PRECISE, int EPI, int BM>
+// PRECISE: 0 = bf16 A operand; 2 = fp32 A split exactly into bf16 hi + lo on the fly (2 MFMAs per fragment: fp32-class);
+// 3 = hi + mid + lo (3 MFMAs: every product exact with bf16-exact weights - the LM prefill, whose ids must track fp32)
+template <int PRECISE, int EPI, int BM>
 __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ Av, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
     extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
     constexpr int NT = BM * 2;                               // threads: (BM/64) x 2 waves, each a 64x64 tile
-    constexpr int A_ELEMS = (PRECISE ? 2 : 1) * BM * GM_PITCH, B_ELEMS = GM_BN * GM_PITCH, BUF = A_ELEMS + B_ELEMS;
+    constexpr int A_ELEMS = (PRECISE ? PRECISE : 1) * BM * GM_PITCH, B_ELEMS = GM_BN * GM_PITCH, BUF = A_ELEMS + B_ELEMS;
     constexpr int A_LOADS = BM * 8 / NT, B_LOADS = GM_BN * 8 / NT;      // 16-B chunks per thread per tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1, lr = lane & 31, kh = lane >> 5;
@@ -121,7 +143,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
     const bf16_t* Ab = (const bf16_t*)Av;
     const float* Af = (const float*)Av;
 
-    uint4 ra[A_LOADS], ral[A_LOADS], rb[B_LOADS];
+    uint4 ra[A_LOADS], ral[A_LOADS], ram[PRECISE == 3 ? A_LOADS : 1], rb[B_LOADS];
     auto load_tile = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
@@ -134,7 +156,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
                     x0 = *reinterpret_cast<const float4*>(p);
                     x1 = *reinterpret_cast<const float4*>(p + 4);
                 }
-                split8(x0, x1, ra[i], ral[i]);
+                if (PRECISE == 3) split8_3(x0, x1, ra[i], ram[i], ral[i]); else split8(x0, x1, ra[i], ral[i]);
             } else {
                 ra[i] = gm < M ? *reinterpret_cast<const uint4*>(Ab + (long)gm * lda + k0 + kc) : make_uint4(0, 0, 0, 0);
             }
@@ -152,6 +174,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
             int idx = tid + i * NT, row = idx >> 3, kc = (idx & 7) * 8;
             *reinterpret_cast<uint4*>(buf + row * GM_PITCH + kc) = ra[i];
             if (PRECISE) *reinterpret_cast<uint4*>(buf + BM * GM_PITCH + row * GM_PITCH + kc) = ral[i];
+            if (PRECISE == 3) *reinterpret_cast<uint4*>(buf + 2 * BM * GM_PITCH + row * GM_PITCH + kc) = ram[i];
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
@@ -179,12 +202,13 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
         const bf16_t* Bs = As + A_ELEMS;
 #pragma unroll
         for (int ks = 0; ks < GM_BK / 16; ++ks) {
-            frag_ab a[2], al[2], b[2];
+            frag_ab a[2], al[2], am[2], b[2];
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 int off = (wm * 64 + mi * 32 + lr) * GM_PITCH + ks * 16 + kh * 8;
                 a[mi] = *reinterpret_cast<const frag_ab*>(As + off);
                 if (PRECISE) al[mi] = *reinterpret_cast<const frag_ab*>(As + BM * GM_PITCH + off);
+                if (PRECISE == 3) am[mi] = *reinterpret_cast<const frag_ab*>(As + 2 * BM * GM_PITCH + off);
             }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
@@ -194,6 +218,7 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    if (PRECISE == 3) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], b[ni], acc[mi][ni], 0, 0, 0);
                     if (PRECISE) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], b[ni], acc[mi][ni], 0, 0, 0);
                 }
         }
@@ -385,10 +410,10 @@ static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int
     return FY_OK;
 }
 
-template <bool PRECISE, int EPI, int BM>
+template <int PRECISE, int EPI, int BM>
 static int gemm_launch3(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = (size_t)2 * ((PRECISE ? 2 : 1) * BM + GM_BN) * GM_PITCH * sizeof(bf16_t);
+    const size_t lds = (size_t)2 * ((PRECISE ? PRECISE : 1) * BM + GM_BN) * GM_PITCH * sizeof(bf16_t);
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_k<PRECISE, EPI, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -401,7 +426,7 @@ static int gemm_launch3(const void* A, int lda, const bf16_t* W, int M, int N, i
 
 // Which kernel: the LDS-DMA ring - 256x128 tiles when they cover most of the chip, 128x128 tiles for smaller grids; the
 // register-staged 128x128x64 kernel for N % 128 != 0 and for the split operand of the precise form.
-template <bool PRECISE, int EPI>
+template <int PRECISE, int EPI>
 static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     if (gemm_tile_override == 64) return gemm_launch3<PRECISE, EPI, 64>(A, lda, W, M, N, K, epi, st);
     // Measured on MI355X with tests/micro/gemm_bench (us; register-staged 128x128x64 / ring 256x256, one workgroup per CU /
@@ -428,7 +453,7 @@ static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, i
     return gemm_launch3<PRECISE, EPI, 128>(A, lda, W, M, N, K, epi, st);
 }
 
-template <bool PRECISE>
+template <int PRECISE>
 static int gemm_launch(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     if (epi.mode == EPI_GATE_RESID) return gemm_launch2<PRECISE, 3>(A, lda, W, M, N, K, epi, st);
     if (!epi.out_bf16) {
@@ -453,12 +478,18 @@ static int gemm_check(const void* A, int lda, const bf16_t* W, int M, int N, int
 int gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     FY_TRY(gemm_check(A, lda, W, M, N, K, epi, 2));
     ProfScope prof("gemm_bf16", 2.0 * M * N * K, st);
-    return gemm_launch<false>(A, lda, W, M, N, K, epi, st);
+    return gemm_launch<0>(A, lda, W, M, N, K, epi, st);
 }
 
 int gemm_f32a_precise(const float* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     FY_TRY(gemm_check(A, lda, W, M, N, K, epi, 4));
-    return gemm_launch<true>(A, lda, W, M, N, K, epi, st);
+    return gemm_launch<2>(A, lda, W, M, N, K, epi, st);
+}
+
+int gemm_f32a_exact(const float* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
+    FY_TRY(gemm_check(A, lda, W, M, N, K, epi, 4));
+    ProfScope prof("gemm_exact", 2.0 * M * N * K, st);
+    return gemm_launch<3>(A, lda, W, M, N, K, epi, st);
 }
 
 __global__ void cast_f32_bf16_k(const float* __restrict__ s, bf16_t* __restrict__ d, size_t n) {

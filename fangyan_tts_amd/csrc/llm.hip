@@ -18,6 +18,8 @@
 struct LlmLayerW {
     bf16_t *wqkv, *wo, *wgu, *wd;
     float *bqkv, *ln1, *ln2;
+    // row-major bf16 copies [N][K] for the prefill GEMMs (many rows: the 8-row GEMV form would re-stream the weights per group)
+    bf16_t *rqkv = nullptr, *ro = nullptr, *rgu = nullptr, *rd = nullptr;
 };
 
 struct fy_llm {
@@ -43,7 +45,10 @@ struct fy_llm {
     int B = 0;
     int step_next = 0, steps_cap = 0;      // fy_llm_begin / fy_llm_step: next decode step of the generation in progress, and its bound
     bool all_done = false;                 // every sequence of that generation has ended: further steps are no-ops
+    float *gu = nullptr, *actf = nullptr, *ones = nullptr;   // prefill GEMM path: gate/up products [rows][2 inter], SwiGLU [rows][inter], a vector of ones (the gate of h += W x)
     DecodePlan* dec = nullptr;             // persistent one-launch decode step (llm_decode.hip) when the architecture fits
+    int prefill_gemm_rows = 320;           // FY_LLM_PREFILL_GEMM_ROWS: from this many prefill rows on, the tiled GEMMs
+    bool prefill_gemm = true;              // FY_LLM_PREFILL_GEMM=0 keeps the 8-row products for the prefill too (A/B measurements)
     int decode_mode = 1;                   // fy_llm_set_decode_mode: 1 = use it, 0 = one launch per operation
     int n_speech() const { return cfg.speech_tokens + 200; }
     int qkv_dim() const { return (cfg.q_heads + 2 * cfg.kv_heads) * cfg.head_dim; }
@@ -380,6 +385,20 @@ __global__ __launch_bounds__(256) void sample_ras_k(const float* __restrict__ lo
     }
 }
 
+// act[r][i] = silu(gu[r][2i]) * gu[r][2i+1]: the gate / up rows are interleaved (Qwen2MLP: down(silu(gate(x)) * up(x)))
+__global__ void swiglu_rows_k(const float* __restrict__ gu, float* __restrict__ act, long n, int inter) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / inter;
+        const int c = (int)(i % inter);
+        const float2 p = *reinterpret_cast<const float2*>(gu + r * 2 * inter + 2 * c);
+        act[i] = act_silu(p.x) * p.y;
+    }
+}
+__global__ void fill_k(float* p, float v, int n) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 // ---- create -------------------------------------------------------------------------------------------------
 static int to_bf16(fy_llm* l, const float* src, size_t n, bf16_t** dst, hipStream_t st) {
     FY_TRY(l->pool.alloc(dst, n));
@@ -420,6 +439,8 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
         return fail(FY_ERR_ARG);
     }
     l->max_batch = max_batch; l->max_ctx = max_ctx; l->max_rows = max_batch * max_ctx;
+    if (const char* e = getenv("FY_LLM_PREFILL_GEMM")) l->prefill_gemm = atoi(e) != 0;
+    if (const char* e = getenv("FY_LLM_PREFILL_GEMM_ROWS")) l->prefill_gemm_rows = std::max(1, atoi(e));
     Weights W;
     int rc = W.init(weights, n_weights);
     if (rc) return fail(rc);
@@ -464,6 +485,10 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
             hipLaunchKernelGGL(interleave_gu_k, dim3(4096), dim3(256), 0, st, gw, uw, tmpg, I, H);
             rc2 = to_packed(l, tmpg, 2 * I, H, &k.wgu, st);
         }
+        if (rc2 == FY_OK) rc2 = to_bf16(l, tmp, (size_t)(Q + 2 * KV) * H, &k.rqkv, st);
+        if (rc2 == FY_OK) rc2 = to_bf16(l, tmpg, (size_t)2 * I * H, &k.rgu, st);
+        if (rc2 == FY_OK) rc2 = to_bf16(l, ow, (size_t)H * Q, &k.ro, st);
+        if (rc2 == FY_OK) rc2 = to_bf16(l, dw, (size_t)H * I, &k.rd, st);
         if (rc2 == FY_OK && l->dec) {
             DecodeLayerSrc ds;
             ds.wqkv = tmp; ds.wo = ow; ds.wgu = tmpg; ds.wd = dw; ds.bqkv = k.bqkv; ds.ln1 = n1; ds.ln2 = n2;
@@ -506,6 +531,8 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
     TRYC(l->pool.alloc(&l->counters, gemv_counter_ints((int)R, H, I) + 16));
     if (hipMemsetAsync(l->counters, 0, (gemv_counter_ints((int)R, H, I) + 16) * sizeof(int), st) != hipSuccess) { fy_set_error("fy_llm_create: memset failed"); return fail(FY_ERR_HIP); }
     TRYC(l->pool.alloc(&l->logp_keep, (size_t)FY_LLM_KEEP_LOGP * B * NS));
+    TRYC(l->pool.alloc(&l->gu, R * 2 * (size_t)I)); TRYC(l->pool.alloc(&l->actf, R * (size_t)I)); TRYC(l->pool.alloc(&l->ones, (size_t)H));
+    hipLaunchKernelGGL(fill_k, dim3(cdiv(H, 256)), dim3(256), 0, st, l->ones, 1.0f, H);
     TRYC(l->pool.alloc(&l->row_seq, R)); TRYC(l->pool.alloc(&l->row_pos, R)); TRYC(l->pool.alloc(&l->row_src, R));
     TRYC(l->pool.alloc(&l->last_row, B)); TRYC(l->pool.alloc(&l->st, 8 * B)); TRYC(l->pool.alloc(&l->seq_ids, B));
     {
@@ -534,10 +561,35 @@ extern "C" void fy_llm_destroy(fy_llm* l) {
 static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, bool decode, hipStream_t st) {
     const fy_llm_config& c = l->cfg;
     const int H = c.hidden, I = c.inter, QKV = l->qkv_dim();
+    // Prefill over many rows: tiled MFMA GEMMs with the activations split EXACTLY three ways (gemm_f32a_exact) - the same
+    // fidelity as the 8-row products below, which at R rows would stream every weight matrix ceil(R / 8) times.
+    // Measured (tests/prefill_probe.py, CosyVoice3-0.5B): 4 x 296 rows 14.9 ms against 42.8; 8 x ~25 rows 10.0 against 7.1 (a
+    // handful of 128-row tiles leaves the chip empty) - the crossover is near 300 rows.
+    const bool gemm_path = !decode && R >= l->prefill_gemm_rows && H % 64 == 0 && I % 64 == 0 && l->prefill_gemm;
     for (int i = 0; i < c.layers; ++i) {
         const LlmLayerW& k = l->L[i];
         float* Kc = l->Kc + (size_t)i * l->cache_layer();
         float* Vc = l->Vc + (size_t)i * l->cache_layer();
+        if (gemm_path) {
+            hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln1, l->xn, R, H, c.rms_eps);
+            GemmEpi q;
+            q.bias = k.bqkv; q.out = l->qkv; q.out_bf16 = 0; q.ldc = QKV;
+            FY_TRY(gemm_f32a_exact(l->xn, H, k.rqkv, R, QKV, H, q, st));
+            hipLaunchKernelGGL(rope_kv_k, dim3(R), dim3(256), 0, st, l->qkv, Kc, Vc, row_seq, row_pos, l->inv_freq, c.q_heads, c.kv_heads, l->max_ctx);
+            FY_TRY(llm_attention(l->qkv, QKV, Kc, Vc, row_seq, row_pos, l->ao, H, R, c.q_heads, c.kv_heads, l->max_ctx, st));
+            GemmEpi o;
+            o.mode = EPI_GATE_RESID; o.resid = l->h; o.gate = l->ones; o.ldc = H;
+            FY_TRY(gemm_f32a_exact(l->ao, H, k.ro, R, H, H, o, st));
+            hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln2, l->xn, R, H, c.rms_eps);
+            GemmEpi g;
+            g.out = l->gu; g.out_bf16 = 0; g.ldc = 2 * I;
+            FY_TRY(gemm_f32a_exact(l->xn, H, k.rgu, R, 2 * I, H, g, st));
+            hipLaunchKernelGGL(swiglu_rows_k, dim3(std::min(4096, cdiv(R * I, 256))), dim3(256), 0, st, l->gu, l->actf, (long)R * I, I);
+            GemmEpi d;
+            d.mode = EPI_GATE_RESID; d.resid = l->h; d.gate = l->ones; d.ldc = H;
+            FY_TRY(gemm_f32a_exact(l->actf, I, k.rd, R, H, I, d, st));
+            continue;
+        }
         GemvArgs a;          // input RMSNorm fused into the projection
         a.W = k.wqkv; a.x = l->h; a.ldx = H; a.R = R; a.N = QKV; a.K = H; a.bias = k.bqkv; a.y = l->qkv; a.ldy = QKV;
         a.norm_w = k.ln1; a.eps = c.rms_eps;

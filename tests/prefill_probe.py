@@ -1,4 +1,5 @@
-"""Not a test: how much of the B = 8 LM time is the prefill?  python tests/prefill_probe.py (through gpurun)"""
+"""Not a test: LM prefill time, tiled exact-split GEMMs against the 8-row products (FY_LLM_PREFILL_GEMM=0), at the benchmark's
+instruct shape (8 sequences x ~25 rows) and the zero-shot shape (4 x 296 rows).  python tests/prefill_probe.py (through gpurun)"""
 import os
 import sys
 import time
@@ -14,16 +15,29 @@ from fangyan_tts_amd.spec import ModelCfg
 dev = torch.device("cuda:0")
 cfg = ModelCfg()
 sd = synth.state_dict_torch(cfg.llm.manifest(), dev, skip=("lm_head",))
-llm = LlmEngine(sd, cfg.llm, max_batch=8, max_ctx=2 + 64 + bench.P_TOK + bench.N_TOK)
 inputs = bench.make_inputs(cfg, 0)
 text = [d["text"].reshape(-1).tolist() for d in inputs]
 ptext = [d["prompt_text"].reshape(-1).tolist() for d in inputs]
-print("prefill rows per sequence:", [2 + len(a) + len(b) for a, b in zip(text, ptext)])
-for n in (1, 2, 9, 75):
-    for rep in range(3):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        llm.generate(text, ptext, [[] for _ in inputs], min_len=[n] * 8, max_len=[n] * 8)
-        torch.cuda.synchronize()
-        dt = 1e3 * (time.perf_counter() - t0)
-    print(f"generate with {n:2d} tokens: {dt:.2f} ms", flush=True)
+hi = 151643
+zs_text = [synth.randint(f"pp.t{b}", (1, 14), 0, hi)[0].tolist() for b in range(4)]
+zs_ptext = [synth.randint(f"pp.p{b}", (1, 30), 0, hi)[0].tolist() for b in range(4)]
+zs_ptok = [synth.randint(f"pp.k{b}", (1, 250), 0, 6561)[0].tolist() for b in range(4)]
+outs = {}
+for mode in ("1", "0"):
+    os.environ["FY_LLM_PREFILL_GEMM"] = mode
+    llm = LlmEngine(sd, cfg.llm, max_batch=8, max_ctx=2 + 64 + 250 + bench.N_TOK)
+    for name, (t, p, k) in (("instruct 8 x ~25 rows", (text, ptext, [[] for _ in text])), ("zero-shot 4 x 296 rows", (zs_text, zs_ptext, zs_ptok))):
+        B = len(t)
+        for n in (1, 12):
+            for rep in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out, out_n, _ = llm.generate(t, p, k, min_len=[n] * B, max_len=[n] * B)
+                torch.cuda.synchronize()
+                dt = 1e3 * (time.perf_counter() - t0)
+            if n == 12:
+                outs[(mode, name)] = out.cpu()
+            print(f"prefill_gemm={mode} {name}: prefill + {n} token(s) {dt:.2f} ms", flush=True)
+    llm.close()
+for name in ("instruct 8 x ~25 rows", "zero-shot 4 x 296 rows"):
+    print(name, "ids equal between the two prefill paths:", bool(torch.equal(outs[("1", name)], outs[("0", name)])))

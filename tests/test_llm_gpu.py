@@ -102,6 +102,25 @@ def test_full_size_behind_a_250_token_prompt(_full250, request):
         run_cases(_mode(_full250, persistent), f, [(14, 30, 250)], 40, f"sized.{'persistent' if persistent else 'per-op'}")
 
 
+def test_prefill_gemm_path_equals_the_8_row_products(monkeypatch):
+    """The tiled exact-split GEMM prefill (used from ~300 rows on) and the 8-row products give the same ids and first
+    log-probabilities, at the reduced size where both are forced on the same 2 x 40-row prefill."""
+    cfg = LlmCfg.tiny()
+    cases = [(12, 8, 0), (10, 6, 30)]
+    texts, ptexts, ptoks = (list(x) for x in zip(*[llm_case(cfg, *c, "%d_%d_%d" % c) for c in cases]))
+    res = []
+    for rows in ("1", "100000"):
+        monkeypatch.setenv("FY_LLM_PREFILL_GEMM_ROWS", rows)
+        eng = make(cfg)
+        out, out_n, _ = eng.generate(texts, ptexts, ptoks, max_len=[60, 60])
+        res.append((out.cpu(), out_n.cpu(), eng.logp(0, 2).cpu()))
+        eng.close()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float((res[0][2] - res[1][2]).abs().max()) < 2e-3
+    f = golden("llm_tiny.npz")
+    assert res[0][0][0, : int(res[0][1][0])].tolist() == f["c12_8_0.tokens"].tolist()[: int(res[0][1][0])]
+
+
 @pytest.fixture(scope="module")
 def _full250():
     return make(LlmCfg(), max_batch=1, max_ctx=2 + 44 + 250 + 64)
