@@ -71,8 +71,8 @@ struct DecArgs {
     bf16_t* img_ao;       // A image of the attention output
     float* ssq_u;         // [H/8][8]  partial sums of squares per 8-column unit (P0 / P5 producers)
     float* ssq_o;         // [H/16][8] per o-proj tile
-    float* qkv;           // [8][QKV]
-    float* part;          // [G][8][H] down-projection partial sums
+    unsigned long long* qkv;   // [8][QKV] granules {tag = epoch of this layer's qkv phase, fp32 bits}: attention polls its own inputs
+    float* part;          // [G][H/8 units][8 rows][8 columns] down-projection partial sums
     float* logits;        // [B][NS]
     const int* st;        // handle state block: row 0 = positions
     const float* inv_freq;
@@ -516,12 +516,17 @@ __device__ __forceinline__ void s_main(const DecArgs& a, char* smem, const int g
             if (hasq[t] && stid < 128) {
                 const int s = stid >> 4, col = stid & 15, n = qt[t] * 16 + col;
                 const float v = s_combine(red, t, s, col) * rstd[s] + ly.bq[n];
-                st_sc1(a.qkv + s * QKV + n, v);
+                __hip_atomic_store(a.qkv + s * QKV + n, ((unsigned long long)(epoch + 1) << 32) | __float_as_uint(v), RLX, AGT);
             }
         }
         stamp();                                            // P1 epilogue issued
-        if (!s_handoff<C>(a, c, smem, epoch)) return;
-        stamp();                                            // P1 hand-off done
+        // No grid hand-off here: an attention unit needs the q / k / v of ONE head - 12 producer tiles - so the values travel
+        // as 8-byte {tag, value} granules written by one write-through store each (the data is the flag,
+        // MI355X_MICROARCH.md R2) and the unit polls its own 192 of them; no drain, no flag round trip.  The epoch still
+        // advances: it is the tag.  (The S waves meet once: the partial-sum region becomes the attention scratch.)
+        ++epoch;
+        sbar(c.cnt, c.gen, lane);
+        stamp();                                            // P1 -> P2
         // ================= P2: attention over the cache, one (sequence, head) per iteration =================
         s_small_dma<C::KF, TO>(ly.wo, ot, haso, small, c);  // this layer's o-proj tile(s): the qkv product has read the buffer (b2)
         {
@@ -536,10 +541,22 @@ __device__ __forceinline__ void s_main(const DecArgs& a, char* smem, const int g
                 const int pos = act ? a.st[s] : 0;
                 float qv = 0.f, kv = 0.f, vv = 0.f;
                 if (act) {
-                    const float* row = a.qkv + (long)s * QKV;
-                    qv = ld_sc1(row + hq * 64 + lane);
-                    kv = ld_sc1(row + (a.Hq + hk) * 64 + lane);
-                    vv = ld_sc1(row + (a.Hq + a.Hk + hk) * 64 + lane);
+                    const unsigned long long* row = a.qkv + (long)s * QKV;
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        const unsigned long long gq = __hip_atomic_load(row + hq * 64 + lane, RLX, AGT);
+                        const unsigned long long gk = __hip_atomic_load(row + (a.Hq + hk) * 64 + lane, RLX, AGT);
+                        const unsigned long long gv = __hip_atomic_load(row + (a.Hq + a.Hk + hk) * 64 + lane, RLX, AGT);
+                        qv = __uint_as_float((unsigned)gq); kv = __uint_as_float((unsigned)gk); vv = __uint_as_float((unsigned)gv);
+                        if (__all((unsigned)(gq >> 32) == epoch && (unsigned)(gk >> 32) == epoch && (unsigned)(gv >> 32) == epoch)) break;
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) {      // 1 s: a producer never arrived
+                            if (lane == 0) {
+                                *(volatile __attribute__((address_space(3))) int*)(smem + C::OFF_MISC + 32) = 1;
+                                __hip_atomic_store(a.status, 2u, RLX, AGT);
+                            }
+                            break;
+                        }
+                    }
                 }
                 const float ang = (float)pos * a.inv_freq[lane & 31];
                 float sn, cs;
@@ -709,9 +726,13 @@ __device__ __forceinline__ void s_main(const DecArgs& a, char* smem, const int g
         wgb();                                              // b2b: ybuf = this workgroup's partial of the 8 x H outputs
         stamp();                                            // P4 down products done
         {
-            const u32x4_t* yb = reinterpret_cast<const u32x4_t*>(ybuf);
-            for (int i = stid; i < 8 * H / 4; i += 256)
-                __builtin_amdgcn_raw_buffer_store_b128(yb[i], c.r_part, (g * 8 * H + i * 4) * 4, 0, SC1);
+            // stored per 8-column unit: part[g][unit][8 rows][8 columns], so that the reduction reads whole 128-byte lines
+            // (with rows of H floats a reducer's 32-byte pieces sat in 40 different lines per wave load)
+            for (int i = stid; i < 8 * H / 4; i += 256) {
+                const int u = i >> 4, r = (i & 15) >> 1, half = i & 1;
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ybuf + r * H + 8 * u + 4 * half);
+                __builtin_amdgcn_raw_buffer_store_b128(v, c.r_part, (g * 8 * H + i * 4) * 4, 0, SC1);
+            }
         }
         stamp();                                            // P4 partial stores issued
         drain_vm();
@@ -731,7 +752,7 @@ __device__ __forceinline__ void s_main(const DecArgs& a, char* smem, const int g
 #pragma unroll
                 for (int i = 0; i < PER_MAX; ++i)
                     if (i < per && g0 + i < g1)
-                        v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c.r_part, (((g0 + i) * 8 + s) * H + 8 * u + 4 * half) * 4, 0, SC1));
+                        v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(c.r_part, ((g0 + i) * 8 * H + u * 64 + s * 8 + 4 * half) * 4, 0, SC1));
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int i = 0; i < PER_MAX; ++i)
@@ -822,7 +843,8 @@ struct DecodePlan {
     bf16_t* w_head = nullptr;
     float* norm_w = nullptr;
     bf16_t *img_h = nullptr, *img_ao = nullptr;
-    float *ssq_u = nullptr, *ssq_o = nullptr, *qkv = nullptr, *part = nullptr;
+    float *ssq_u = nullptr, *ssq_o = nullptr, *part = nullptr;
+    unsigned long long* qkv = nullptr;
     unsigned *flags = nullptr, *status = nullptr;
     unsigned epoch = 0;
     size_t lds = 0;
@@ -885,7 +907,7 @@ int decode_create(DecodePlan** out, const DecodeShape& s, hipStream_t st) {
 #undef TRYP
     if (hipMemsetAsync(p->flags, 0, (((p->G + 3) / 4) * 4 + 4) * 4, st) != hipSuccess || hipMemsetAsync(p->status, 0, 16, st) != hipSuccess ||
         hipMemsetAsync(p->img_h, 0, IMG, st) != hipSuccess || hipMemsetAsync(p->img_ao, 0, IMG, st) != hipSuccess ||
-        hipMemsetAsync(p->part, 0, (size_t)p->G * 8 * s.H * 4, st) != hipSuccess || hipMemsetAsync(p->qkv, 0, (size_t)8 * s.qkv() * 4, st) != hipSuccess) {
+        hipMemsetAsync(p->part, 0, (size_t)p->G * 8 * s.H * 4, st) != hipSuccess || hipMemsetAsync(p->qkv, 0, (size_t)8 * s.qkv() * 8, st) != hipSuccess) {
         fy_set_error("decode_create: memset failed");
         return fail(FY_ERR_HIP);
     }

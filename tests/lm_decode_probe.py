@@ -52,7 +52,7 @@ llm.generate(text, ptext, [[] for _ in range(8)], min_len=[20] * 8, max_len=[20]
 torch.cuda.synchronize()
 L.fy_debug_decode_stamps(llm._h, buf, N, st)
 t = [int(x) for x in buf]
-names = ["P1 staged", "P1 products", "P1 epilogue", "P1 hand-off", "P2 attention", "P2 hand-off", "P3 staged", "P3 products", "P3 epilogue",
+names = ["P1 staged", "P1 products", "P1 epilogue", "P1 -> P2 (granules, no hand-off)", "P2 attention", "P2 hand-off", "P3 staged", "P3 products", "P3 epilogue",
          "P3 hand-off", "P4 staged", "P4 gate/up", "P4 swiglu", "P4 down", "P4 stores", "P4 hand-off", "P5 reduce", "P5 hand-off"]
 print(f"P0 + hand-off: {(t[1] - t[0]) / 100:.2f} us")
 for layer in (0, 1, 12, 23):
