@@ -24,9 +24,15 @@ struct GemmEpi {
     // [rope_stride, rope_stride + 2*rope_half) at position (row % rope_T), table [rope_T][rope_half] of (cos, sin)
     const float2* rope = nullptr;
     int rope_T = 0, rope_half = 0, rope_stride = 0;
+#ifdef FY_GEMM_STAMPS
+    int stamp_slot = 0;                // tests/micro/gemm_stamps.hip: which 4096-workgroup slot of the stamp buffer this launch writes
+#endif
 };
+#ifdef FY_GEMM_STAMPS
+void gemm_set_stamps(unsigned long long* p);
+#endif
 
-extern int gemm_tile_override;     // microbenchmarks: 0 auto; 128 / 64 register-staged kernel with that M tile; 2 / 3 / 256 ring kernel with 256x128 / 128x128 / 256x256 tiles
+extern int gemm_tile_override;     // microbenchmarks only: 0 = automatic choice (gemm.hip lists the forms)
 // A: bf16 [M][lda]; W: bf16 [N][K] (K % 64 == 0); M, N arbitrary
 int gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st);
 // A: fp32 [M][lda], split into bf16 hi + lo on the fly (fp32-class accuracy when W is bf16-exact)

@@ -6,7 +6,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
 #define GM_BM 128
-int gemm_tile_override = 0;        // microbenchmarks: 0 auto; 128 / 64 register-staged kernel with that M tile; 2 / 3 / 256 ring kernel with 256x128 / 128x128 / 256x256 tiles
+int gemm_tile_override = 0;        // microbenchmarks: 0 auto; 128 / 64 register-staged kernel with that M tile; ring kernel: 2 / 3 = 256x128 / 128x128 tiles, 2002 / 2003 the same on 16x16x32 MFMAs, 256 / 320 = 256x256 / 320x256, 1256 / 1320 those with staggered wave groups
 #define GM_BN 128
 #define GM_BK 64
 #define GM_PITCH 72          // bf16 elements per LDS row: 64 + 8 pad (144 B: 16-B aligned, spreads ds_read_b128 over banks)
@@ -242,19 +242,35 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
 // row r lives at slot c ^ ((r >> 2) & 3).  Counted s_waitcnt vmcnt(4) + raw s_barrier keep a stage in flight across
 // the barrier (__syncthreads() would drain them).
 #define G2_BK 32
+// chunk c (16 bytes) of tile row r lives at slot c ^ G2_SW(r) of the row's 64 bytes: conflict-free for the fragment reads of both
+// MFMA shapes (32x32x16: 32 rows x one chunk per half-wave; 16x16x32: 16 rows x all four chunks)
+#define G2_SW(row) ((0 - ((row) >> 2)) & 3)
+// -DFY_GEMM_STAMPS (tests/micro/gemm_bench.hip): wave 0 of every workgroup records the 100 MHz clock at entry, when the first
+// stage has landed, after the K loop and after the epilogue
+#ifdef FY_GEMM_STAMPS
+__device__ unsigned long long* gemm_stamp_buf;
+void gemm_set_stamps(unsigned long long* p) { hipMemcpyToSymbol(HIP_SYMBOL(gemm_stamp_buf), &p, sizeof(p)); }
+#define G2_STAMP(i) do { if (tid == 0 && gemm_stamp_buf) gemm_stamp_buf[(e.stamp_slot * 4096 + blockIdx.x) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define G2_STAMP(i) do { } while (0)
+#endif
 #define G2_RING_BYTES (96 * 1024)                            // BN 256: three 32 KB stages; BN 128: three 24 KB stages = 72 KB, so that two workgroups share a CU
 
-// BN = 256: 8 waves as 2 (M) x 4 (N), 128x64 per wave.  BN = 128: 4 x 2 waves of 64x64, <= 128 VGPRs and a 72 KB ring, so
-// two workgroups are resident per CU: one's prologue / epilogue bursts run under the other's K loop (the four DiT
-// products of a block: 184 -> 168 us), and the N = 1024 products get twice the tiles.
-template <int EPI, int BN, int BM = 256>
+// BN = 256: 8 waves as 2 (M) x 4 (N), 128x64 (BM 256) or 160x64 (BM 320) per wave.  BN = 128: 4 x 2 waves of 64x64, <= 128 VGPRs
+// and a 72 KB ring, so two workgroups are resident per CU: one's prologue / epilogue bursts run under the other's K loop (the
+// four DiT products of a block: 184 -> 168 us), and the N = 1024 products get twice the tiles.
+// STAG: the two wave groups of a one-per-CU workgroup run half a K step apart (comment at the loop).  MF = 1: the products on
+// v_mfma_f32_16x16x32_bf16 instead of 32x32x16 - the same cycles per flop, the same bits out, but the chip holds a higher clock
+// on it (MI355X_MICROARCH.md, DVFS give-back item 7): 5-19 % less time at two or more workgroups per CU.
+template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0>
 __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
     extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
     char* smem = reinterpret_cast<char*>(gm_smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NWAVE = BM == 128 ? 4 : 8;                             // BM 128 (with BN 128): 2 x 2 waves of 64x64, 48 KB ring, three workgroups per CU
     constexpr int WN = BN / 64, WM = NWAVE / WN, MI = BM / WM / 32;       // waves along N / M, 32-row tiles per wave
-    constexpr int STAGE = (BM + BN) * G2_BK * 2, STAGES = (BN == 128 ? 3 : G2_RING_BYTES / STAGE), NB = BN / (NWAVE * 16);   // NB: B DMAs per wave and stage
+    constexpr int STAGE = (BM + BN) * G2_BK * 2, STAGES = 3, NB = BN / (NWAVE * 16);   // NB: B DMAs per wave and stage
+    constexpr int NA_ALL = BM / 16, NA = (NA_ALL + NWAVE - 1) / NWAVE, NA_LAST = NA_ALL - (NA - 1) * NWAVE;   // A DMAs: wave-instruction j = i * NWAVE + wid fills rows [16 j, 16 j + 16); the last round only on waves < NA_LAST
     constexpr int BOFF = BM * G2_BK * 2;                                  // the B tile follows the A tile inside a stage
     const int wm = wid / WN, wn = wid % WN, lr = lane & 31, kh = lane >> 5;
     // XCD-aware tile order (see gemm_bf16_k)
@@ -262,26 +278,29 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+    G2_STAMP(0);
 
-    // wave-instruction i (of 2) of wave wid fills stage bytes [(wid*2+i)*1024, +1024) of the A (and B) tile:
-    // row = (wid*2+i)*16 + lane/4, slot = lane%4  ->  logical chunk = slot ^ ((row >> 2) & 3)
-    const bf16_t* a_src[2];
+    // wave-instruction j fills stage bytes [j * 1024, +1024) of the A (and B) tile:
+    // row = j*16 + lane/4, slot = lane%4  ->  logical chunk = slot ^ ((row >> 2) & 3)
+    const bf16_t* a_src[NA];
     const bf16_t* b_src[NB];
+    const bool a_last = NA_LAST == NWAVE || wid < NA_LAST;           // wave-uniform: this wave takes part in the last round of A DMAs
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wid * 2 + i) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+    for (int i = 0; i < NA; ++i) {
+        const int row = (i * NWAVE + wid) * 16 + (lane >> 2), c = (lane & 3) ^ G2_SW(row);
         a_src[i] = A + (long)min(m0 + row, M - 1) * lda + c * 8;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int row = (wid * NB + i) * 16 + (lane >> 2), c = (lane & 3) ^ ((row >> 2) & 3);
+        const int row = (wid * NB + i) * 16 + (lane >> 2), c = (lane & 3) ^ G2_SW(row);
         b_src[i] = W + (long)min(n0 + row, N - 1) * K + c * 8;
     }
     auto issue = [&](int t) {
         char* st = smem + (t % STAGES) * STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(a_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + wid * 2048 + i * 1024), 16, 0, 0);
+        for (int i = 0; i < NA; ++i)
+            if (i + 1 < NA || a_last)
+                __builtin_amdgcn_global_load_lds((const void*)(a_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + (i * NWAVE + wid) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             __builtin_amdgcn_global_load_lds((const void*)(b_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + BOFF + wid * NB * 1024 + i * 1024), 16, 0, 0);
@@ -298,25 +317,133 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     // fragment read offsets inside a stage (bytes): row*64 + ((2ks + kh) ^ ((row>>2)&3))*16
     int a_off[MI], b_off[2], a_sw[MI], b_sw[2];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) { const int ra = wm * (MI * 32) + i * 32 + lr; a_off[i] = ra * 64; a_sw[i] = (ra >> 2) & 3; }
+    for (int i = 0; i < MI; ++i) { const int ra = wm * (MI * 32) + i * 32 + lr; a_off[i] = ra * 64; a_sw[i] = G2_SW(ra); }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int rb = wn * 64 + i * 32 + lr; b_off[i] = BOFF + rb * 64; b_sw[i] = (rb >> 2) & 3; }
+    for (int i = 0; i < 2; ++i) { const int rb = wn * 64 + i * 32 + lr; b_off[i] = BOFF + rb * 64; b_sw[i] = G2_SW(rb); }
+    // the 16x16x32 form: fragment i covers 16 rows, lane l reads row (l & 15), chunk (l >> 4): one read per fragment and K step
+    int a16[MF ? 2 * MI : 1], b16[MF ? 4 : 1];
+    f32x4 acc4[MF ? 2 * MI : 1][4];
+    if constexpr (MF) {
+#pragma unroll
+        for (int i = 0; i < 2 * MI; ++i) { const int ra = wm * (MI * 32) + i * 16 + (lane & 15); a16[i] = ra * 64 + (((lane >> 4) ^ G2_SW(ra)) << 4); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int rb = wn * 64 + i * 16 + (lane & 15); b16[i] = BOFF + rb * 64 + (((lane >> 4) ^ G2_SW(rb)) << 4); }
+#pragma unroll
+        for (int i = 0; i < 2 * MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     const int nt = K / G2_BK;
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
         if (t < nt) issue(t);
+    if constexpr (STAG) {
+        // One workgroup per CU: its two waves on a SIMD (wid and wid + 4) would read fragments together and run MFMAs together,
+        // each waiting while the other kind of work could run.  Here the K step is cut into a read interval and an MFMA interval
+        // with a barrier after each, and waves 4-7 run one interval behind waves 0-3: on every SIMD one wave reads while the
+        // other computes.  Interval numbering I_k (between barriers k-1 and k), K step t:
+        //   waves 0-3: I_2t   issue(t+2), read fragments(t)              I_2t+1  MFMAs(t), wait for own DMAs of stage t+1
+        //   waves 4-7: I_2t+1 read fragments(t), wait for stage t+1      I_2t+2  issue(t+3), MFMAs(t)
+        // Stage t+2 (or t+3) goes into the slot of stage t-1 (t), which both groups have read before barrier 2t-1 (2t+1);
+        // every wave has waited for its DMAs of stage t before barrier 2t-1, one barrier before the first read of it.
+        constexpr int D = NA + NB;
+        auto wait_stage = [&](int t) {
+            if (t >= nt) return;
+            if (t + 1 >= nt) __builtin_amdgcn_s_waitcnt(0x0F70);
+            else if (a_last) __builtin_amdgcn_s_waitcnt(0x0F70 | D);
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | (D - 1));
+        };
+        frag_ab fa[2][MI], fb[2][2];
+        auto reads = [&](int t) {
+            const char* sb = smem + (t % STAGES) * STAGE;
+            if constexpr (MF) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j >> 1][j & 1] = *reinterpret_cast<const frag_ab*>(sb + b16[j]);
+#pragma unroll
+                for (int i = 0; i < 2 * MI; ++i) fa[i & 1][i >> 1] = *reinterpret_cast<const frag_ab*>(sb + a16[i]);
+            } else
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) fb[ks][ni] = *reinterpret_cast<const frag_ab*>(sb + b_off[ni] + (((2 * ks + kh) ^ b_sw[ni]) << 4));
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) fa[ks][mi] = *reinterpret_cast<const frag_ab*>(sb + a_off[mi] + (((2 * ks + kh) ^ a_sw[mi]) << 4));
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the slot may be refilled after the next barrier
+        };
+        auto mfmas = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+            if constexpr (MF) {
+#pragma unroll
+                for (int i = 0; i < 2 * MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i & 1][i >> 1], fb[j >> 1][j & 1], acc4[i][j], 0, 0, 0);
+            } else
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mi], fb[ks][ni], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        wait_stage(0);
+        __builtin_amdgcn_s_barrier();                               // barrier -1
+        G2_STAMP(1);
+        if (wid < NWAVE / 2) {
+            for (int t = 0; t < nt; ++t) {
+                if (t + 2 < nt) issue(t + 2);
+                reads(t);
+                __builtin_amdgcn_s_barrier();                       // 2t
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas();
+                wait_stage(t + 1);
+                __builtin_amdgcn_s_barrier();                       // 2t + 1
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_barrier();                           // 2 nt: the other group's last interval
+        } else {
+            if (2 < nt) issue(2);
+            __builtin_amdgcn_s_barrier();                           // 0
+            for (int t = 0; t < nt; ++t) {
+                reads(t);
+                wait_stage(t + 1);
+                __builtin_amdgcn_s_barrier();                       // 2t + 1
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 3 < nt) issue(t + 3);
+                mfmas();
+                __builtin_amdgcn_s_barrier();                       // 2t + 2
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else
     for (int t = 0; t < nt; ++t) {
         // stage t has landed once at most the stages issued after it are still outstanding (2 + NB DMAs per stage per wave)
         const int ahead = min(nt - 1 - t, STAGES - 2);
-        constexpr int D = 2 + NB;
-        if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * D));   // vmcnt(2 D): D <= 4, so the count fits the low four bits
-        else if (ahead == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | D);
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                         // vmcnt(0)
+        constexpr int D = NA + NB;                                       // DMAs per stage of a wave that takes part in every round (2 D <= 15: the count fits the low four bits)
+        if (ahead == 0) __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+        else if (a_last) { if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * D)); else __builtin_amdgcn_s_waitcnt(0x0F70 | D); }
+        else { if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (D - 1))); else __builtin_amdgcn_s_waitcnt(0x0F70 | (D - 1)); }
         __builtin_amdgcn_s_barrier();                               // everyone's part of stage t is in LDS; the slot of stage t-1 is free
+        if (t == 0) G2_STAMP(1);
         if (t + STAGES - 1 < nt) issue(t + STAGES - 1);
         const char* sb = smem + (t % STAGES) * STAGE;
         frag_ab fa[2][MI], fb[2][2];
+        if constexpr (MF) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j >> 1][j & 1] = *reinterpret_cast<const frag_ab*>(sb + b16[j]);
+#pragma unroll
+            for (int i = 0; i < 2 * MI; ++i) fa[i & 1][i >> 1] = *reinterpret_cast<const frag_ab*>(sb + a16[i]);
+#pragma unroll
+            for (int i = 0; i < 2 * MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i & 1][i >> 1], fb[j >> 1][j & 1], acc4[i][j], 0, 0, 0);
+            continue;
+        }
         auto load_frags = [&](int ks, frag_ab (&a)[MI], frag_ab (&b)[2]) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) b[ni] = *reinterpret_cast<const frag_ab*>(sb + b_off[ni] + (((2 * ks + kh) ^ b_sw[ni]) << 4));
@@ -335,6 +462,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
         }
     }
     __syncthreads();                                                // all waves are done with the ring: the epilogue parks tiles in it
+    G2_STAMP(2);
 
     // epilogue through LDS, a quarter of the wave's tile (32 rows x 64 columns) at a time: see gemm_epilogue
     float* park = reinterpret_cast<float*>(smem) + wid * 32 * 68;
@@ -345,6 +473,14 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     if (EPI == 3) gv = *reinterpret_cast<const float4*>(e.gate + n);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+        if constexpr (MF) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) park[(i * 16 + 4 * (lane >> 4) + r) * 68 + j * 16 + (lane & 15)] = acc4[2 * mi + i][j][r];
+        } else
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -394,18 +530,19 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
             }
         }
     }
+    G2_STAMP(3);
 }
 
-template <int EPI, int BN, int BM = 256>
+template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0>
 static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = BN == 128 ? (size_t)3 * (BM + BN) * G2_BK * 2 : (size_t)G2_RING_BYTES;   // BN 128: 72 KB (two workgroups per CU) or 48 KB (three)
+    const size_t lds = (size_t)3 * (BM + BN) * G2_BK * 2;          // 256x256: 96 KB; 320x256: 108 KB (one workgroup per CU); 256x128: 72 KB (two); 128x128: 48 KB (three)
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN, BM, STAG, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid((N / BN) * cdiv(M, BM));
-    hipLaunchKernelGGL((gemm256_k<EPI, BN, BM>), grid, dim3(BM == 128 ? 256 : 512), lds, st, A, lda, W, M, N, K, epi);
+    hipLaunchKernelGGL((gemm256_k<EPI, BN, BM, STAG, MF>), grid, dim3(BM == 128 ? 256 : 512), lds, st, A, lda, W, M, N, K, epi);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -429,13 +566,17 @@ static int gemm_launch3(const void* A, int lda, const bf16_t* W, int M, int N, i
 template <int PRECISE, int EPI>
 static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     if (gemm_tile_override == 64) return gemm_launch3<PRECISE, EPI, 64>(A, lda, W, M, N, K, epi, st);
-    // Measured on MI355X with tests/micro/gemm_bench (us; register-staged 128x128x64 / ring 256x256, one workgroup per CU /
-    // ring 256x128, two per CU):
-    //   M 6400:  N 3072 K 1024: 68 / 70 / 57    N 2048 K 1024: 58 / 42 / 42    N 1024 K 1024: 32 / 37 / 27    N 1024 K 2048: 48 / 62 / 42
-    //   M 12800: N 3072 K 1024: 119 / 115 / 97  N 2048 K 1024: 95 / 87 / 83    N 1024 K 1024: 47 / 38 / 38
-    //   M 3200:  N 3072 K 1024: 41 / 39 / 37    N 1024 K 1024: 21.6 / 36 / 22.8   N 1024 K 2048: 34 / 61 / 37   (104 tiles: too few)
-    // The 256x256 tile is ~15 % faster inside the K loop but never ahead overall: every tile pays ~10 us of prologue /
-    // epilogue bursts, which only a second resident workgroup hides; it stays selectable for the microbenchmark.
+    // Measured on MI355X with tests/micro/gemm_bench (round 2; us, M = 6400 unless noted; tests/micro/gemm_stamps.hip gives the
+    // per-workgroup timeline).  What the timeline says: a K step runs at ~80 % of what the MFMAs allow at the clock the chip
+    // holds under this load (1.5-1.7 GHz, not 2.4); the rest of a launch is the tile count against the CU count, ~6 us of
+    // memory-bound epilogue that every workgroup enters at the same time, and 1-3 us of prologue and launch gap.
+    //   tiling (workgroups per CU)         qkv N 3072   out N 1024   ff1 N 2048   ff2 N 1024 K 2048
+    //   256x128 (2), 32x32x16 MFMA             58.9         27.9         43.1         43.5
+    //   256x128 (2), 16x16x32 MFMA             56.1         27.5         40.7         43.3       the chip holds a higher clock on this shape
+    //   128x128 (3), 32x32x16 / 16x16x32    58.7 / 56.1  27.6 / 24.3  51.5 / 48.8  42.3 / 37.0   (M 3200: 18.8 / 19.8 and 29.4 / 31.3)
+    //   256x256 (1), plain / staggered      72.9 / 70.1  38.3 / 36.4  45.1 / 42.2  62.6 / 58.8   300 tiles: two rounds
+    //   320x256 (1), staggered                 47.5         44.0         49.1         70.1       240 tiles: one round
+    // All tilings give bit-identical outputs (K is accumulated in the same order; checked by gemm_bench).
     if (!PRECISE && gemm_tile_override != 128 && N % 128 == 0 && K % G2_BK == 0) {
         static int cus = 0;
         if (!cus) {
@@ -443,12 +584,22 @@ static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, i
             hipDeviceProp_t p;
             cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
         }
-        if (gemm_tile_override == 256 && N % 256 == 0) return gemm_launch_256<EPI, 256>((const bf16_t*)A, lda, W, M, N, K, epi, st);
-        const int t128 = (N / 128) * cdiv(M, 256);
-        if (gemm_tile_override == 2 || (gemm_tile_override == 0 && 5 * t128 >= 3 * cus)) return gemm_launch_256<EPI, 128>((const bf16_t*)A, lda, W, M, N, K, epi, st);
-        // fewer tiles than that: the same ring with 128x128 tiles (4 waves, 48 KB, three workgroups per CU) - at M = 3200
-        // 18 / 29 / 36 us for the out / ff2 / qkv shapes against 21 / 34 / 41 with the register-staged kernel
-        return gemm_launch_256<EPI, 128, 128>((const bf16_t*)A, lda, W, M, N, K, epi, st);
+        const bf16_t* Ab = (const bf16_t*)A;
+        const int ov = gemm_tile_override;
+        if (ov == 256 && N % 256 == 0) return gemm_launch_256<EPI, 256>(Ab, lda, W, M, N, K, epi, st);
+        if (ov == 320 && N % 256 == 0) return gemm_launch_256<EPI, 256, 320>(Ab, lda, W, M, N, K, epi, st);
+        if (ov == 1256 && N % 256 == 0) return gemm_launch_256<EPI, 256, 256, 1>(Ab, lda, W, M, N, K, epi, st);
+        if (ov == 2) return gemm_launch_256<EPI, 128>(Ab, lda, W, M, N, K, epi, st);
+        if (ov == 3) return gemm_launch_256<EPI, 128, 128>(Ab, lda, W, M, N, K, epi, st);
+        const int t128 = (N / 128) * cdiv(M, 256), t64 = (N / 128) * cdiv(M, 128), t320 = N % 256 ? 0 : (N / 256) * cdiv(M, 320);
+        // 320x256 tiles, one workgroup per CU, when they cover the chip in ONE round where 256x128 tiles would need a second one
+        if ((ov == 1320 && N % 256 == 0) || (ov == 0 && t128 > 2 * cus && t320 <= cus && 20 * t320 >= 17 * cus)) return gemm_launch_256<EPI, 256, 320, 1>(Ab, lda, W, M, N, K, epi, st);
+        // 256x128 tiles (two workgroups per CU: one's prologue / epilogue bursts run under the other's K loop) from one tile per CU on
+        if (ov == 2002 || (ov == 0 && t128 >= cus)) return gemm_launch_256<EPI, 128, 256, 0, 1>(Ab, lda, W, M, N, K, epi, st);
+        // fewer tiles than that: 128x128 tiles (4 waves, 48 KB, three workgroups per CU); the 16x16x32 form reads a K step's
+        // fragments in one go, which costs a workgroup that is alone on its CU more than the clock gains
+        if (ov == 2003 || (ov == 0 && 2 * t64 >= 3 * cus)) return gemm_launch_256<EPI, 128, 128, 0, 1>(Ab, lda, W, M, N, K, epi, st);
+        return gemm_launch_256<EPI, 128, 128>(Ab, lda, W, M, N, K, epi, st);
     }
     return gemm_launch3<PRECISE, EPI, 128>(A, lda, W, M, N, K, epi, st);
 }

@@ -1,7 +1,10 @@
 // Stand-alone GEMM microbenchmark (DiT shapes).  Not part of the library.
 #include "gemm.h"
 #include "runtime.h"
+#include <algorithm>
 #include <functional>
+#include <math.h>
+#include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -37,8 +40,30 @@ int main(int argc, char** argv) {
         {12800, 1024, 1024, 0, "M=12800 bf16 out"}, {12800, 3072, 1024, 0, "M=12800 qkv"}, {12800, 2048, 1024, 0, "M=12800 ff1"}, {3200, 3072, 1024, 0, "M=3200 qkv"}, {3200, 1024, 1024, 1, "M=3200 out"}, {3200, 1024, 2048, 1, "M=3200 ff2"}, {6400, 1024, 320, 2, "in-proj f32 out"}};
     extern int gemm_tile_override;
     if (pmc) g_warm = 1;
-    for (int tile : {128, 0, 2, 3}) {
-        if (pmc && tile) continue; gemm_tile_override = tile; printf("--- tile override %d (128: register-staged 128x128x64 only; 0: automatic choice; 2 / 3: LDS-DMA ring with 256x128 / 128x128 tiles wherever it applies)\n", tile);
+    if (!pmc) {   // every tiling accumulates K in the same order: the outputs must be bit-identical to the automatic choice's
+        for (auto& s : shapes) {
+            if (s.mode != 0) continue;
+            std::vector<bf16_t> ref((size_t)s.M * s.N), got(ref.size());
+            for (int tile : {0, 256, 320, 1256, 1320, 2002, 2003, 2, 3, 128}) {
+                if (tile >= 256 && tile < 2000 && s.N % 256) continue;
+                gemm_tile_override = tile;
+                GemmEpi e; e.bias = bias; e.out = O; e.out_bf16 = 1; e.ldc = s.N; e.act = s.N == 2048 ? ACT_GELU_TANH : ACT_NONE;
+                hipMemsetAsync(O, 0xff, ref.size() * 2, st);
+                gemm_bf16(A, s.K, W, s.M, s.N, s.K, e, st);
+                hipStreamSynchronize(st);
+                hipMemcpy(tile ? got.data() : ref.data(), O, ref.size() * 2, hipMemcpyDeviceToHost);
+                if (tile) {
+                    size_t bad = 0; double maxd = 0;
+                    auto f = [](bf16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
+                    for (size_t i = 0; i < ref.size(); ++i) { bad += ref[i] != got[i]; maxd = std::max(maxd, (double)fabsf(f(ref[i]) - f(got[i]))); }
+                    if (tile >= 2000) { printf("check %-20s tile %4d (16x16x32 MFMA: another summation order inside the instruction): %zu of %zu outputs differ by at most %.3g\n", s.name, tile, bad, ref.size(), maxd); continue; }
+                    printf("check %-20s M %5d N %4d K %4d tile %3d: %zu of %zu outputs differ from the automatic tiling%s\n", s.name, s.M, s.N, s.K, tile, bad, ref.size(), bad ? "  <-- MISMATCH" : "");
+                }
+            }
+        }
+    }
+    for (int tile : {0, 2, 2002, 3, 2003, 1320}) {
+        if (pmc && tile) continue; gemm_tile_override = tile; printf("--- tile override %d (0: automatic choice; 2 / 3: LDS-DMA ring with 256x128 / 128x128 tiles; 2002 / 2003: the same on 16x16x32 MFMAs; 1320: 320x256 tiles, staggered wave groups)\n", tile);
     for (auto& s : shapes) {
         GemmEpi e;
         e.bias = bias;
