@@ -7,13 +7,13 @@
 //                     (query row, query head); serves prefill rows and decode steps alike
 //                     (transformers Qwen2Attention as called from llm/llm.py:246-258).
 #include "attn.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
 #define AT_D 64
 #define AT_KP 72             // bf16 elements per LDS row of the K tile (64 + 8 pad: conflict-free ds_read_b128 rows)
 #define AT_VP 96             // V tile pitch: 48 dwords, so the four rows of a transposed 4x16 block sit 16 banks apart
-#define AT_NW 4              // waves per workgroup, 32 queries each
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
@@ -24,10 +24,14 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // product follows the accumulator's register order (key 16s + 8(j>>2) + 4h + (j&3) in element j of lane half h); the
 // A operand V^T is read to match, transposed by the LDS itself (ds_read_b64_tr_b16 on the row-major V tile).
 // qkv: bf16 [nseq*Tmax][3*H*64] as [q | k | v]; out: bf16 [nseq*Tmax][H*64]
-__global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void dit_attention_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+template <int AT_NW, int WPE>
+__global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void dit_attention_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                               const int* __restrict__ seq_len, int Tmax, int H, int chunk, float scale_log2) {
     __shared__ __attribute__((aligned(16))) bf16_t Kbuf[2][64 * AT_KP];      // two tiles: the next one is written while this one is read,
     __shared__ __attribute__((aligned(16))) bf16_t Vbuf[2][64 * AT_VP];      // one barrier per key tile
+    // the many-wave form runs at 4 waves per SIMD (128 registers): the query fragments wait in LDS instead of 16 registers
+    constexpr bool QL = AT_NW > 4;
+    __shared__ __attribute__((aligned(16))) bf16_t Qbuf[QL ? AT_NW * 32 * AT_KP : 8];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (AT_NW * 32);
     const int len = seq_len[s];
@@ -37,9 +41,12 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3
     const int lr = lane & 31, hf = lane >> 5;
     const int qrow = q0 + wid * 32 + lr;                     // this lane's query
     frag_ab qf[4];                                           // B[k = 16ks + 8hf + j][col = query]
+    bf16_t* Qs = Qbuf + (QL ? (wid * 32 + lr) * AT_KP + hf * 8 : 0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
+    for (int ks = 0; ks < 4; ++ks) {
         qf[ks] = *reinterpret_cast<const frag_ab*>(base + (long)min(qrow, len - 1) * ld + h * AT_D + ks * 16 + hf * 8);
+        if (QL) *reinterpret_cast<frag_ab*>(Qs + ks * 16) = qf[ks];      // read back by the same lane only
+    }
     f32x16 o[2];                                             // O^T[d = 32dt + (r&3) + 8(r>>2) + 4hf][query]
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -50,18 +57,20 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3
     int kend = len;
     if (chunk > 0) kend = min(len, ((min(q0 + AT_NW * 32 - 1, len - 1) / chunk) + 1) * chunk);
     const int lim = chunk > 0 ? min(len, ((min(qrow, len - 1) / chunk) + 1) * chunk) : len;   // keys < lim are visible to this query
-    // K/V tiles are fetched one tile ahead into registers: the loads of tile t+1 fly under the MFMAs of tile t
-    constexpr int NLD = 512 / (AT_NW * 64);                  // 16-byte chunks of a 64 x 64 bf16 tile per thread
-    uint4 kreg[NLD], vreg[NLD];
+    // K/V tiles are fetched one tile ahead into registers: the loads of tile t+1 fly under the MFMAs of tile t.  A tile is
+    // 2 x 512 16-byte chunks (64 keys x 8 chunks of K, then of V); chunk c = tid + i * threads
+    constexpr int NT = AT_NW * 64, NLD = (1024 + NT - 1) / NT;
+    uint4 kvreg[NLD];
     auto load_kv = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * (AT_NW * 64), key = idx >> 3, dc = (idx & 7) * 8;
-            const bool ok = k0 + key < len;
-            const bf16_t* p = base + (long)min(k0 + key, len - 1) * ld + h * AT_D + dc;
-            kreg[i] = *reinterpret_cast<const uint4*>(p + H * AT_D);
-            vreg[i] = *reinterpret_cast<const uint4*>(p + 2 * H * AT_D);
-            if (!ok) { kreg[i] = make_uint4(0, 0, 0, 0); vreg[i] = kreg[i]; }
+            const int c = tid + i * NT, idx = c & 511, key = idx >> 3, dc = (idx & 7) * 8;
+            if (1024 % NT == 0 || c < 1024) {
+                const bool ok = k0 + key < len;
+                const bf16_t* p = base + (long)min(k0 + key, len - 1) * ld + h * AT_D + dc + (c < 512 ? 1 : 2) * H * AT_D;
+                kvreg[i] = *reinterpret_cast<const uint4*>(p);
+                if (!ok) kvreg[i] = make_uint4(0, 0, 0, 0);
+            }
         }
     };
     // transposed V read: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4-key x 16-d block and
@@ -71,9 +80,11 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3
     auto store_kv = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * (AT_NW * 64), key = idx >> 3, dc = (idx & 7) * 8;
-            *reinterpret_cast<uint4*>(Kbuf[buf] + key * AT_KP + dc) = kreg[i];
-            *reinterpret_cast<uint4*>(Vbuf[buf] + key * AT_VP + dc) = vreg[i];
+            const int c = tid + i * NT, idx = c & 511, key = idx >> 3, dc = (idx & 7) * 8;
+            if (1024 % NT == 0 || c < 1024) {
+                if (c < 512) *reinterpret_cast<uint4*>(Kbuf[buf] + key * AT_KP + dc) = kvreg[i];
+                else *reinterpret_cast<uint4*>(Vbuf[buf] + key * AT_VP + dc) = kvreg[i];
+            }
         }
     };
     const bool wave_live = q0 + wid * 32 < len;              // a wave past the sequence end only helps staging
@@ -95,7 +106,8 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 frag_ab kf = *reinterpret_cast<const frag_ab*>(Ks + (kt * 32 + lr) * AT_KP + ks * 16 + hf * 8);
-                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kt], 0, 0, 0);
+                const frag_ab q = QL ? *reinterpret_cast<const frag_ab*>(Qs + ks * 16) : qf[ks];
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, q, sc[kt], 0, 0, 0);
             }
         }
         frag_ab pf[2][2];                                    // P^T as the B operand: [kt][k-step s] = registers 8s .. 8s+7
@@ -184,8 +196,37 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(3, 3
 
 int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st) {
     FY_CHECK(qkv && out && seq_len && nseq >= 1 && Tmax >= 1 && H >= 1, FY_ERR_ARG, "dit_attention: bad arguments");
-    dim3 grid(cdiv(Tmax, AT_NW * 32), H, nseq);
-    hipLaunchKernelGGL(dit_attention_k, grid, dim3(AT_NW * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, 0.125f * 1.4426950408889634f);
+    const float sl2 = 0.125f * 1.4426950408889634f;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    static const int force = getenv("FY_ATTN_WAVES") ? atoi(getenv("FY_ATTN_WAVES")) : 0;   // experiments and the equality test
+    // Queries are cut into 32-row waves; the waves of a workgroup share the K/V tiles of their (sequence, head).  With 4-wave
+    // workgroups (3 per CU) T = 400 gives 4 x H x nseq workgroups, a quarter of them with ONE live wave, and 1024 of them on 768
+    // places take two rounds: 33.9 us per call at batch 8.  When a (sequence, head) fits one workgroup of <= 16 waves and those
+    // workgroups cover at least half the CUs, one workgroup takes all of a pair's queries (4 waves per SIMD, Q fragments in LDS):
+    // K/V are staged once per pair and the grid is a single round - 27.5 us (rocprofv3 over bench.py --no-pipeline).  From 8 waves
+    // on the form needs no spill at 128 registers.
+    const int nw = cdiv(Tmax, 32);
+    int W = 4;                                                   // waves per workgroup
+    if (force) W = force;
+    else if (nw >= 8 && nw <= 16 && H * nseq >= cus / 2) W = nw;
+    if (W <= 4) {
+        dim3 grid(cdiv(Tmax, 4 * 32), H, nseq);
+        hipLaunchKernelGGL((dit_attention_k<4, 3>), grid, dim3(4 * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2);
+    } else {
+        dim3 grid(cdiv(nw, W), H, nseq);
+#define FY_ATT_CASE(N) case N: hipLaunchKernelGGL((dit_attention_k<N, 4>), grid, dim3(N * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2); break;
+        switch (W) {
+            FY_ATT_CASE(8) FY_ATT_CASE(9) FY_ATT_CASE(10) FY_ATT_CASE(11) FY_ATT_CASE(12)
+            FY_ATT_CASE(13) FY_ATT_CASE(14) FY_ATT_CASE(15) FY_ATT_CASE(16)
+            default: FY_CHECK(false, FY_ERR_ARG, "dit_attention: %d waves per workgroup", W);
+        }
+#undef FY_ATT_CASE
+    }
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }

@@ -2,6 +2,7 @@
 #include "gemm.h"
 #include "runtime.h"
 #include <algorithm>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 
@@ -585,7 +586,8 @@ static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, i
             cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
         }
         const bf16_t* Ab = (const bf16_t*)A;
-        const int ov = gemm_tile_override;
+        static const int env_ov = getenv("FY_GEMM_TILE") ? atoi(getenv("FY_GEMM_TILE")) : 0;   // experiments: a tiling for every product
+        const int ov = gemm_tile_override ? gemm_tile_override : env_ov;
         if (ov == 256 && N % 256 == 0) return gemm_launch_256<EPI, 256>(Ab, lda, W, M, N, K, epi, st);
         if (ov == 320 && N % 256 == 0) return gemm_launch_256<EPI, 256, 320>(Ab, lda, W, M, N, K, epi, st);
         if (ov == 1256 && N % 256 == 0) return gemm_launch_256<EPI, 256, 256, 1>(Ab, lda, W, M, N, K, epi, st);
