@@ -177,6 +177,32 @@ def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, steps=3):
     return out
 
 
+def bench_latency_b1(cfg, sd_llm, sd_flow, sd_hift, dev, inputs, reps=4):
+    """BASELINE.json configs[0]'s shape as a secondary object: ONE utterance alone (5 s prompt, 75 forced tokens = 3 s of audio)
+    through tts_batch, wav on the host - what a single request waits (the LM decodes with the persistent one-launch-per-token step)."""
+    from fangyan_tts_amd import synth
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    m = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=1, max_text=64, max_prompt_tokens=P_TOK, max_tokens=N_TOK,
+                        rand_noise=torch.from_numpy(synth.flow_rand_noise(2 * (P_TOK + N_TOK))).to(dev),
+                        rand_ini=torch.from_numpy(synth.hift_rand_ini()).to(dev),
+                        sine_noise=torch.from_numpy(synth.hift_sine_noise(2 * N_TOK * 480)).to(dev))
+    one = inputs[:1]
+    m.tts_batch(one, min_len=[N_TOK], max_len=[N_TOK])
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        wav, samples, _ = m.tts_batch(one, min_len=[N_TOK], max_len=[N_TOK])
+        ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[len(ts) // 2]
+    out = {"workload": "one utterance alone (batch 1, 5 s prompt, 75 forced tokens), wav on the host", "ms": round(1e3 * dt, 2),
+           "audio_s": round(samples[0] / 24000.0, 2), "times_real_time": round(samples[0] / 24000.0 / dt, 1),
+           "lm_decode": "persistent" if m.llm.persistent else "per-op"}
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -324,13 +350,13 @@ def main():
     ms, flops, n = prof["gemm_bf16"]
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     # HBM-side traffic per launch of the same kernel on the same shapes: PMC counters cannot be read from
-    # inside this process, so the figure is the one rocprofv3 measured (profiles/r01_gemm_pmc.json says how)
-    traffic, pmc = None, os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
+    # inside this process, so the figure is the one rocprofv3 measured (profiles/r02_gemm_pmc.json says how)
+    traffic, pmc = None, os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")
     if os.path.exists(pmc):
         traffic = json.load(open(pmc)).get("dit_mix_traffic_bytes_per_launch")
-    roofline = {"bound": "mfma", "kernel": "DiT linears: gemm256_k (LDS-DMA ring, 256x128x32 tiles, two workgroups per CU); 128x128 ring tiles for small grids", "achieved": round(achieved, 2),
+    roofline = {"bound": "mfma", "kernel": "DiT linears: gemm256_k (LDS-DMA ring; per shape 320x256 tiles with staggered wave groups, 256x128 or 128x128 tiles on 16x16x32 MFMAs)", "achieved": round(achieved, 2),
                 "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "bytes per launch (rocprofv3 PMC, profiles/r01_gemm_pmc.json)",
+                "traffic_unit": "bytes per launch (rocprofv3 PMC on the stand-alone driver, profiles/r02_gemm_pmc.json)",
                 "launches_per_step": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
                 "gflop_per_launch": round(flops / max(n, 1) / 1e9, 3),
                 "measured_over": "HIP events on the launch stream around every launch of one step run alone after the timed region",
@@ -420,7 +446,9 @@ def main():
         "roofline_dit_linears": roofline,
     }
     if rank == 0 and world == 1 and not a.no_extras:
-        # behind the timed region: BASELINE.json configs[2] and configs[4] as secondary objects of the same record
+        # behind the timed region: BASELINE.json configs[0], configs[2] and configs[4] as secondary objects of the same record
+        log("one utterance alone (config 1's shape)")
+        out["latency_b1"] = bench_latency_b1(cfg, sd_llm, sd_flow, sd_hift, dev, inputs)
         log("zero-shot batch 4 (config 3)")
         out["zero_shot_b4"] = bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev)
         log("HiFT-only 32 x 10 000 frames (config 5)")

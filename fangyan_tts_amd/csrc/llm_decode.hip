@@ -539,6 +539,10 @@ __device__ __forceinline__ void s_main(const DecArgs& a, char* smem, const int g
                 const int s = u / a.Hq, hq = u - s * a.Hq, hk = hq / grp;
                 const bool act = s < B;
                 const int pos = act ? a.st[s] : 0;
+                // what does not depend on this step's q / k / v goes first: the rotation angles
+                const float ang = (float)pos * a.inv_freq[lane & 31];
+                float sn, cs;
+                sincosf(ang, &sn, &cs);
                 float qv = 0.f, kv = 0.f, vv = 0.f;
                 if (act) {
                     const unsigned long long* row = a.qkv + (long)s * QKV;
@@ -558,9 +562,6 @@ __device__ __forceinline__ void s_main(const DecArgs& a, char* smem, const int g
                         }
                     }
                 }
-                const float ang = (float)pos * a.inv_freq[lane & 31];
-                float sn, cs;
-                sincosf(ang, &sn, &cs);
                 const float qo = __shfl_xor(qv, 32, 64), ko = __shfl_xor(kv, 32, 64);
                 const float qr = lane < 32 ? qv * cs - qo * sn : qv * cs + qo * sn;
                 const float kr = lane < 32 ? kv * cs - ko * sn : kv * cs + ko * sn;

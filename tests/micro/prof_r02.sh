@@ -1,12 +1,11 @@
 # Round 2 profiles.  Run on the GPU box from the repository root (through gpurun):  bash tests/micro/prof_r02.sh
 # 1. rocprofv3 --kernel-trace --stats over the default bench command and over --no-pipeline (where the single LM stream uses
 #    the persistent decode kernel) -> per-kernel summaries (copied to profiles/ afterwards);
-# 2. HBM-side traffic by PMC, FETCH_SIZE and WRITE_SIZE in separate passes, over the SAME bench.py process.  Round 1 could not
-#    do that (SIGSEGV in the first torch launch): the torch wheel brings its own libamdhip64.so / libhsa-runtime64.so and asks
-#    for them by FILE name, the rocprofv3 tool has /opt/rocm's libhsa-runtime64.so.1 loaded already, whose SONAME does not match
-#    that file name, and the process ended up with TWO HSA runtimes (gpurun_out/pmc_probe_plain.log lists both mapped).
-#    Pre-loading /opt/rocm's copies under the bare file names makes the loader satisfy torch's request with the copy that is
-#    already there: one runtime, counters work (tests/micro/pmc_torch_probe.py).
+# 2. HBM-side traffic of the LM decode kernels by PMC (FETCH_SIZE and WRITE_SIZE in separate passes) over
+#    tests/micro/pmc_lm_probe.py.  bench.py itself cannot run under --pmc: with ONE HSA runtime in the process (the pre-load
+#    below; DESIGN.md section 6 has the analysis) counters work for every kernel of this library and for small torch kernels,
+#    but the profiler still dies in the launch path of torch's large elementwise kernels that fill the synthetic model on the GPU;
+# 3. the DiT products' traffic and MFMA-busy counters (tests/micro/gemm_pmc.py over the stand-alone gemm_bench).
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
@@ -24,14 +23,17 @@ PY
 rocprofv3 --kernel-trace --stats -d /tmp/p_pipe -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extras > $O/r02_bench_under_rocprof.json 2> /tmp/prof.err || (tail -5 /tmp/prof.err; exit 1)
 summ "$(find /tmp/p_pipe -name '*kernel_stats.csv' | head -1)" $O/r02_bench_kernel_stats.csv
 head -8 $O/r02_bench_kernel_stats.csv | cut -c1-140
+echo "[prof] pipelined done"
 rocprofv3 --kernel-trace --stats -d /tmp/p_nopipe -o bench --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-pipeline --steps 5 > $O/r02_bench_nopipeline_under_rocprof.json 2> /tmp/prof.err || (tail -5 /tmp/prof.err; exit 1)
 summ "$(find /tmp/p_nopipe -name '*kernel_stats.csv' | head -1)" $O/r02_bench_nopipeline_kernel_stats.csv
 head -8 $O/r02_bench_nopipeline_kernel_stats.csv | cut -c1-140
+echo "[prof] unpipelined done"
 export LD_LIBRARY_PATH=/opt/rocm/lib LD_PRELOAD="libamdhip64.so libhsa-runtime64.so"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_nopipe_$c -- python3 $R/bench.py --no-cpu-baseline --no-extras --no-pipeline --steps 1 --warmup 1 > /tmp/pmc_$c.json 2> /tmp/pmc_$c.err || (tail -5 /tmp/pmc_$c.err; exit 1)
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_pipe_$c -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 > /tmp/pmcp_$c.json 2> /tmp/pmcp_$c.err || (tail -5 /tmp/pmcp_$c.err; exit 1)
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_lm_$c -- python3 $R/tests/micro/pmc_lm_probe.py > /tmp/pmc_lm_$c.out 2> /tmp/pmc_lm_$c.err || (tail -5 /tmp/pmc_lm_$c.err; exit 1)
 done
 unset LD_PRELOAD LD_LIBRARY_PATH
-python3 $R/tests/micro/pmc_aggregate.py /tmp/pmc_nopipe_FETCH_SIZE /tmp/pmc_nopipe_WRITE_SIZE $O/r02_bench_nopipeline_pmc.json "bench.py --no-pipeline --steps 1 --warmup 1 (persistent LM decode)"
-python3 $R/tests/micro/pmc_aggregate.py /tmp/pmc_pipe_FETCH_SIZE /tmp/pmc_pipe_WRITE_SIZE $O/r02_bench_pmc.json "bench.py --steps 2 --warmup 1 (default, pipelined)"
+python3 $R/tests/micro/pmc_aggregate.py /tmp/pmc_lm_FETCH_SIZE /tmp/pmc_lm_WRITE_SIZE $O/r02_llm_decode_pmc.json "tests/micro/pmc_lm_probe.py: batch 8, 6 tokens, persistent then per-operation decode"
+echo "[prof] LM decode PMC done"
+python3 $R/tests/micro/gemm_pmc.py
+cp $O/gemm_pmc.json $O/r02_gemm_pmc.json
