@@ -472,8 +472,28 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gv = bv;
     if (e.bias) bv = *reinterpret_cast<const float4*>(e.bias + n);
     if (EPI == 3) gv = *reinterpret_cast<const float4*>(e.gate + n);
+    // Rotary embedding (EPI 0): only the lanes whose four columns lie in a rotated range fetch (cos, sin) pairs, and they fetch
+    // a 32-row block's eight table rows in one batch, one block AHEAD of their use (under the previous block's stores) - fetched
+    // where they are used, each row's 16 bytes cost a trip to L2 in the middle of the store loop (qkv at M = 6400: +11 us on the
+    // 320x256 tile, whose epilogue nothing hides).
+    int rope_col = -1;                                              // float2 index of this lane's first pair inside a table row
+    if (EPI == 0 && e.rope) {
+        const int nn = n >= e.rope_stride ? n - e.rope_stride : n;
+        if (n < 2 * e.rope_stride && nn < 2 * e.rope_half) rope_col = nn >> 1;
+    }
+    constexpr bool RAHEAD = BN == 256;                             // the one-per-CU tiles have the registers for it; at 128 they would cost a workgroup per CU
+    float4 rt[8], rn[RAHEAD ? 8 : 1];
+    auto rope_fetch = [&](int mi, float4 (&t)[8]) {
+        if (rope_col < 0) return;
+        const int m00 = m0 + wm * (MI * 32) + mi * 32 + rsub;
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            t[it] = *reinterpret_cast<const float4*>(e.rope + (long)(min(m00 + it * 4, M - 1) % e.rope_T) * e.rope_half + rope_col);
+    };
+    if (EPI == 0 && RAHEAD) rope_fetch(0, rt);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
+        if (EPI == 0 && !RAHEAD) rope_fetch(mi, rt);             // before the block's trip through LDS
         if constexpr (MF) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -500,6 +520,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
 #pragma unroll
         for (int it = 0; it < 8; ++it) vr[it] = make_float4(vq[it][0], vq[it][1], vq[it][2], vq[it][3]);
         __builtin_amdgcn_wave_barrier();                         // the next quarter overwrites the park region
+        if constexpr (EPI == 0 && RAHEAD) { if (mi + 1 < MI) rope_fetch(mi + 1, rn); }     // travels under this block's stores
         const int mb = m0 + wm * (MI * 32) + mi * 32 + rsub;
         float4 old[8];
         if (EPI == 3) {
@@ -523,11 +544,22 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
                 *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
             } else {
                 if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
-                if (EPI == 0 && e.rope) epi_rope(v, e, m, n);
+                if (EPI == 0 && rope_col >= 0) {                 // x-transformers apply_rotary_pos_emb on two interleaved pairs (epi_rope's arithmetic)
+                    const float4 t = rt[it];
+                    const float a = v.x, b = v.y, c = v.z, d = v.w;
+                    v.x = a * t.x - b * t.y; v.y = b * t.x + a * t.y;
+                    v.z = c * t.z - d * t.w; v.w = d * t.z + c * t.w;
+                }
                 uint2 pk;
                 pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
                 pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
                 *reinterpret_cast<uint2*>((bf16_t*)e.out + (long)m * e.ldc + n) = pk;
+            }
+        }
+        if constexpr (EPI == 0 && RAHEAD) {
+            if (rope_col >= 0) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) rt[it] = rn[it];
             }
         }
     }
