@@ -65,8 +65,8 @@ def run(batch=32, frames=10000, steps=3, warmup=1, flags=0):
     frames = a.batch * a.frames
     audio = frames * 480 / 24000.0
     # HBM-side traffic: rocprofv3 --pmc cannot sit under a torch process on this pool, so the per-frame figure is the one
-    # measured on the stand-alone driver of the same engine (profiles/r01_hift_pmc.json says how), scaled to this run
-    traffic, pmc = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hift_pmc.json")
+    # measured on the stand-alone driver of the same engine (profiles/r02_hift_pmc.json says how), scaled to this run
+    traffic, pmc = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_hift_pmc.json")
     if os.path.exists(pmc) and a.flags == 0:
         traffic = int(json.load(open(pmc))["traffic_bytes_per_frame"] * frames)
     bw = frames * BYTES_PER_FRAME / dt
@@ -76,7 +76,7 @@ def run(batch=32, frames=10000, steps=3, warmup=1, flags=0):
         "metric": "HiFT vocoder audio sec/sec", "value": round(audio / dt, 1), "unit": "audio_s/s", "ms_per_step": round(1e3 * dt, 2),
         "config": {"workload": f"HiFT-only, random mel, batch {a.batch} x {a.frames} frames", "flags": a.flags},
         "roofline": {"bound": "hbm", "achieved": round(bw / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(bw / HBM_PEAK, 4),
-                     "traffic": traffic, "traffic_unit": "bytes per step (L2-miss bytes per frame from profiles/r01_hift_pmc.json x frames)",
+                     "traffic": traffic, "traffic_unit": "bytes per step (L2-miss bytes per frame from profiles/r02_hift_pmc.json x frames)",
                      "frac_on_counter_bytes": round(traffic / dt / HBM_PEAK, 4) if traffic else None,
                      "algorithmic_bytes": int(frames * BYTES_PER_FRAME), "algorithmic_tflops": round(frames * FLOP_PER_FRAME / dt / 1e12, 1),
                      "conv_mfma_ms": round(ms, 2), "conv_mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1) if ms else None,

@@ -62,3 +62,26 @@ int conv1d_f32_direct(const ConvDesc& d, const ConvW& w, hipStream_t st);
 int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_t st);
 // exact fp32 on v_mfma_f32_32x32x2_f32 (w.w_dir layout); stride 1, one group; bias, ELU / leaky-relu, residual add
 int conv1d_f32_mfma(const ConvDesc& d, const ConvW& w, hipStream_t st);
+
+// One ResBlock iteration of the HiFT generator in ONE launch (hifigan/generator.py:110-117):
+//     out = conv2(snake(conv1(snake(x; a1)); a2)) + x,        conv1: k taps, dilation d; conv2: k taps, dilation 1; both causal
+// The inner activation never leaves the chip: a workgroup computes conv1 on its rows plus the k-1 rows conv2 needs to the left,
+// rounds snake(.) to bf16 into LDS (the very values conv1's bf16 output stream carried) and runs conv2 from there.  Same MFMA
+// order per output as the two-launch form, so the results are identical bit for bit.  C = 64 or 128 channels.
+struct ResIterDesc {
+    const float* x;            // fp32 input of conv1 (activated with alpha1 while staged) ...
+    const bf16_t* x_act;       // ... or its bf16 stream, already activated by the producer (x_act != null: x is not read)
+    const float* resid;        // the iteration's x, fp32: added to conv2's result
+    long bs; int ld;           // every tensor: element (b, row, c) at base + b*bs + row*ld + c, rows [0, L), ld == C
+    const float* alpha1;       // snake of conv1's input (fp32 input only)
+    const float* alpha2;       // snake between the convs
+    const float* bias1; const float* bias2;
+    int KW, dil;               // taps of both convs, dilation of conv1
+    float* y;                  // fp32 result: y = (conv2 + resid) * out_scale, or y += ... (accumulate); may be null when only y_act is wanted
+    bf16_t* y_act;             // optional: snake(result; alpha_out) rounded to bf16 - the next iteration's conv1 input stream
+    const float* alpha_out;
+    float out_scale; int accumulate;
+    int B, L, C; const int* len;   // rows >= len[b] (null: L) are neither read nor written
+};
+int conv_resblock_iter(const ResIterDesc& d, const ConvW& w1, const ConvW& w2, hipStream_t st);
+bool conv_resblock_iter_supported(int C, int KW, int dil);

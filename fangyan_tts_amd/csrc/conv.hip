@@ -8,6 +8,7 @@
 #include "conv.h"
 #include "runtime.h"
 #include <algorithm>
+#include <stdlib.h>
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
@@ -524,6 +525,257 @@ int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_
         return precise ? launch_mfma<2, 2, true, false>(d, w, st) : launch_mfma<2, 2, false, false>(d, w, st);
     }
     return precise ? launch_mfma<4, 1, true, false>(d, w, st) : launch_mfma<4, 1, false, false>(d, w, st);
+}
+
+// =============================================================================
+// One ResBlock iteration in one launch (conv.h: ResIterDesc).  WP x WC waves: WP*64 rows of conv1's output (= conv2's input,
+// kept in LDS as the activated bf16 values) x WC*64 = C channels - a workgroup owns ALL channels of its rows, which is what
+// lets conv2 follow without leaving the chip.  conv2 produces the last TP - (KW-1) of those rows.  The MFMA order of every
+// accumulator is the one conv1d_bf16_mfma_k uses (taps outer, 16-channel steps inner), so both forms give the same bits.
+// =============================================================================
+template <int WP, int WC, bool INB>
+__global__ __launch_bounds__(WP* WC * 64) void resblock_iter_k(ResIterDesc d, const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2) {
+    constexpr int TP = WP * 64, C = WC * 64, NT = WP * WC * 64;
+    constexpr int ROWB = C * 2 + 16, NK = C / 16, N32 = C / 32, KH = NK / 2, EP = 68;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: conv1's input rows X first; once every wave has read them, conv2's input rows Y [TP] take their place and the
+    // epilogues park their tiles behind Y
+    char* X = smem;
+    char* Y = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wpi = wid / WC, wci = wid % WC, kh = lane >> 5, lr = lane & 31;
+    const int b = blockIdx.z;
+    const int h2 = d.KW - 1, h1 = (d.KW - 1) * d.dil, P2 = TP - h2;
+    const int p0 = blockIdx.x * P2;                          // first output row of this workgroup
+    const int n = d.len ? d.len[b] : d.L;
+    if (p0 >= n) return;
+    const int g0 = p0 - h2 - h1;                             // global row of X row 0
+    const int nrows = TP + h1, row_max = max(n - 1, 0);
+    // ---- stage conv1's input ----
+    if (INB) {
+        constexpr int SBB = 12, q8 = C / 8;
+        const int total8 = nrows * q8;
+        const bf16_t* xa = d.x_act + (long)b * d.bs;
+        for (int base = tid; base < total8; base += NT * SBB) {
+            uint4 vv[SBB];
+            int off[SBB];
+#pragma unroll
+            for (int u = 0; u < SBB; ++u) {
+                const int idx = min(base + u * NT, total8 - 1);
+                const int r = idx / q8, c8 = (idx - r * q8) * 8;
+                const int row = g0 + r;
+                vv[u] = *reinterpret_cast<const uint4*>(xa + (long)min(max(row, 0), row_max) * d.ld + c8);
+                off[u] = (row >= 0 && row < n) ? r * ROWB + c8 * 2 : -1 - (r * ROWB + c8 * 2);
+            }
+#pragma unroll
+            for (int u = 0; u < SBB; ++u) {
+                if (base + u * NT >= total8) break;
+                const bool ok = off[u] >= 0;
+                *reinterpret_cast<uint4*>(X + (ok ? off[u] : -1 - off[u])) = ok ? vv[u] : make_uint4(0, 0, 0, 0);
+            }
+        }
+    } else {
+        constexpr int SB = 4, q4 = C / 4;
+        const int total = nrows * q4;
+        const float* xb = d.x + (long)b * d.bs;
+        for (int base = tid; base < total; base += NT * SB) {
+            float4 vv[SB], aa[SB];
+            int rr[SB], cc[SB];
+            bool okk[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int idx = min(base + u * NT, total - 1);
+                const int r = idx / q4, c4 = (idx - r * q4) * 4;
+                const int row = g0 + r;
+                rr[u] = r; cc[u] = c4;
+                okk[u] = row >= 0 && row < n;
+                vv[u] = *reinterpret_cast<const float4*>(xb + (long)min(max(row, 0), row_max) * d.ld + c4);
+                aa[u] = *reinterpret_cast<const float4*>(d.alpha1 + c4);
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                if (base + u * NT >= total) break;
+                float4 v = vv[u];
+                const float4 a = aa[u];
+                if (!okk[u]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                v.x = snake_fast(v.x, a.x); v.y = snake_fast(v.y, a.y); v.z = snake_fast(v.z, a.z); v.w = snake_fast(v.w, a.w);
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                *reinterpret_cast<uint2*>(X + (size_t)rr[u] * ROWB + cc[u] * 2) = pk;
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+    const int n32_base = wci * 2;
+    // acc += sum over taps t and 16-channel steps of  src[row0 + wpi*64 + mi*32 + lr + t*dil][.] x W[t][.][this wave's 64 columns]
+    auto product = [&](const char* src, const bf16_t* wp, int dil, int last_row) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        auto load_b = [&](int t, int half, frag_ab (&bb)[KH][2]) {
+            const bf16_t* wt = wp + (((long)t * NK + half * KH) * N32 + n32_base) * 512 + lane * 8;
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) {
+                bb[kk][0] = *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512);
+                bb[kk][1] = *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512 + 512);
+            }
+        };
+        auto tap_half = [&](int t, int half, const frag_ab (&bb)[KH][2]) {
+#pragma unroll
+            for (int kk = 0; kk < KH; ++kk) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const size_t off = (size_t)min(wpi * 64 + mi * 32 + lr + t * dil, last_row) * ROWB + ((half * KH + kk) * 16 + kh * 8) * 2;
+                    const frag_ab a = *reinterpret_cast<const frag_ab*>(src + off);
+                    acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb[kk][0], acc[mi][0], 0, 0, 0);
+                    acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb[kk][1], acc[mi][1], 0, 0, 0);
+                }
+            }
+        };
+        frag_ab h0[KH][2], h1[KH][2];
+        load_b(0, 0, h0);
+        for (int t = 0; t < d.KW; ++t) {
+            load_b(t, 1, h1);
+            tap_half(t, 0, h0);
+            if (t + 1 < d.KW) load_b(t + 1, 0, h0);
+            tap_half(t, 1, h1);
+        }
+    };
+    product(X, w1, d.dil, nrows - 1);
+    __syncthreads();                                         // every wave is done with X
+
+    float* et = reinterpret_cast<float*>(smem + (size_t)TP * ROWB) + wid * 32 * EP;
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int co = wci * 64 + c4;
+    {   // conv1's epilogue: bias, snake(alpha2), bf16 -> Y; rows before the sequence start are conv2's zero padding
+        const float4 bv = d.bias1 ? *reinterpret_cast<const float4*>(d.bias1 + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 av = *reinterpret_cast<const float4*>(d.alpha2 + co);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) et[((r & 3) + 8 * (r >> 2) + 4 * kh) * EP + ni * 32 + lr] = acc[mi][ni][r];
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = wpi * 64 + mi * 32 + it * 4 + rsub;
+                float4 v = *reinterpret_cast<const float4*>(et + (it * 4 + rsub) * EP + c4);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                v.x = snake_fast(v.x, av.x); v.y = snake_fast(v.y, av.y); v.z = snake_fast(v.z, av.z); v.w = snake_fast(v.w, av.w);
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                if (p0 - h2 + r < 0) pk = make_uint2(0, 0);
+                *reinterpret_cast<uint2*>(Y + (size_t)r * ROWB + co * 2) = pk;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    product(Y, w2, 1, TP - 1);                               // rows past the tile only feed the KW - 1 masked outputs
+
+    // conv2's epilogue (the plain form of conv1d_bf16_mfma_k's): bias, + x, scale / accumulate, fp32 out and the next conv1's stream
+    float* yb = d.y ? d.y + (long)b * d.bs : nullptr;
+    bf16_t* ya = d.y_act ? d.y_act + (long)b * d.bs : nullptr;
+    const float* rb = d.resid + (long)b * d.bs;
+    const float osc = d.out_scale;
+    const float4 bv = d.bias2 ? *reinterpret_cast<const float4*>(d.bias2 + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 av = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (ya) av = *reinterpret_cast<const float4*>(d.alpha_out + co);
+    const int n_out = min(n, p0 + P2);                       // rows this workgroup writes: [p0, n_out)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) et[((r & 3) + 8 * (r >> 2) + 4 * kh) * EP + ni * 32 + lr] = acc[mi][ni][r];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        const int pbase = p0 + wpi * 64 + mi * 32 + rsub;
+        float4 rv[8], ov[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const long q = min(pbase + it * 4, n_out - 1);
+            rv[it] = *reinterpret_cast<const float4*>(rb + q * d.ld + co);
+            ov[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (d.accumulate && yb) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const long q = min(pbase + it * 4, n_out - 1);
+                ov[it] = *reinterpret_cast<const float4*>(yb + q * d.ld + co);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int p = pbase + it * 4;
+            float4 v = *reinterpret_cast<const float4*>(et + (it * 4 + rsub) * EP + c4);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (p >= n_out) continue;
+            float4 o;
+            o.x = fmaf(v.x + rv[it].x, osc, ov[it].x); o.y = fmaf(v.y + rv[it].y, osc, ov[it].y);
+            o.z = fmaf(v.z + rv[it].z, osc, ov[it].z); o.w = fmaf(v.w + rv[it].w, osc, ov[it].w);
+            if (yb) *reinterpret_cast<float4*>(yb + (long)p * d.ld + co) = o;
+            if (ya) {
+                o.x = snake_fast(o.x, av.x); o.y = snake_fast(o.y, av.y); o.z = snake_fast(o.z, av.z); o.w = snake_fast(o.w, av.w);
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
+                *reinterpret_cast<uint2*>(ya + (long)p * d.ld + co) = pk;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+bool conv_resblock_iter_supported(int C, int KW, int dil) {
+    if (C != 64 && C != 128) return false;
+    const int TP = C == 64 ? 256 : 128, h1 = (KW - 1) * dil, h2 = KW - 1;
+    return KW >= 1 && dil >= 1 && h2 < TP / 2 && (size_t)(TP + h1) * (C * 2 + 16) <= 80 * 1024;
+}
+
+template <int WP, int WC, bool INB>
+static int launch_resblock_iter(const ResIterDesc& d, const ConvW& w1, const ConvW& w2, hipStream_t st) {
+    constexpr int TP = WP * 64, C = WC * 64, ROWB = C * 2 + 16;
+    const int h1 = (d.KW - 1) * d.dil, h2 = d.KW - 1, P2 = TP - h2;
+    // X, then Y in its place with the parked half tiles behind it: <= 80 KB, so two workgroups share a CU and one's staging and
+    // epilogues run under the other's MFMAs
+    const size_t lds = std::max((size_t)(TP + h1) * ROWB, (size_t)TP * ROWB + (size_t)WP * WC * 32 * 68 * sizeof(float));
+    FY_CHECK(lds <= 160 * 1024, FY_ERR_ARG, "conv_resblock_iter: needs %zu B of LDS", lds);
+    auto kern = resblock_iter_k<WP, WC, INB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    ProfScope prof("conv_mfma", 2.0 * 2.0 * d.B * d.L * (double)C * C * d.KW, st);
+    dim3 grid(cdiv(d.L, P2), 1, d.B);
+    hipLaunchKernelGGL(kern, grid, dim3(WP * WC * 64), lds, st, d, w1.w_mfma, w2.w_mfma);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+int conv_resblock_iter(const ResIterDesc& d, const ConvW& w1, const ConvW& w2, hipStream_t st) {
+    FY_CHECK(conv_resblock_iter_supported(d.C, d.KW, d.dil), FY_ERR_ARG, "conv_resblock_iter: C %d, k %d, dilation %d not supported", d.C, d.KW, d.dil);
+    FY_CHECK(w1.w_mfma && w2.w_mfma && w1.Cin == d.C && w1.Cout == d.C && w2.Cin == d.C && w2.Cout == d.C && w1.KW == d.KW && w2.KW == d.KW &&
+             w1.groups == 1 && w2.groups == 1, FY_ERR_ARG, "conv_resblock_iter: weights do not match the descriptor");
+    FY_CHECK((d.x_act || (d.x && d.alpha1)) && d.resid && d.alpha2 && (d.y || d.y_act) && (!d.y_act || d.alpha_out) && (d.y || !d.accumulate),
+             FY_ERR_ARG, "conv_resblock_iter: bad descriptor");
+    FY_CHECK(d.ld == d.C && d.bs % 8 == 0 && d.B >= 1 && d.L >= 1, FY_ERR_ARG, "conv_resblock_iter: tensors must be dense channels-last");
+    FY_CHECK((((uintptr_t)d.x | (uintptr_t)d.x_act | (uintptr_t)d.resid | (uintptr_t)d.y | (uintptr_t)d.y_act) & 15) == 0, FY_ERR_ARG,
+             "conv_resblock_iter: tensors must be 16-B aligned");
+    if (d.C == 64) return d.x_act ? launch_resblock_iter<4, 1, true>(d, w1, w2, st) : launch_resblock_iter<4, 1, false>(d, w1, w2, st);
+    static const bool wide = getenv("FY_HIFT_FUSE_WIDE") && atoi(getenv("FY_HIFT_FUSE_WIDE"));      // experiment: 256-row tiles, one workgroup per CU
+    if (wide) return d.x_act ? launch_resblock_iter<4, 2, true>(d, w1, w2, st) : launch_resblock_iter<4, 2, false>(d, w1, w2, st);
+    return d.x_act ? launch_resblock_iter<2, 2, true>(d, w1, w2, st) : launch_resblock_iter<2, 2, false>(d, w1, w2, st);
 }
 
 // =============================================================================

@@ -5,6 +5,7 @@
 // neighbouring element-wise work (Snake, leaky-relu, nearest upsample, reflect
 // pad, residual, source fusion, the /3 average) folded into it.
 #include "conv.h"
+#include <stdlib.h>
 #include "runtime.h"
 #include <math.h>
 
@@ -489,6 +490,33 @@ static int run_resblock(fy_hift* h, const HiftConvs::RB& rb, const float* x_in, 
     const bool streams = !(flags & (FY_DIRECT | FY_PRECISE)) && rb.c1[0].w_mfma && C % 32 == 0;
     bf16_t* a2 = reinterpret_cast<bf16_t*>(xt);
     bf16_t* a1 = a2 + bs * B;
+    static const bool fuse_on = !(getenv("FY_HIFT_FUSE") && atoi(getenv("FY_HIFT_FUSE")) == 0);
+    bool fuse = streams && fuse_on && !(final_acc && x_in == work);
+    for (int j = 0; j < N_DIL && fuse; ++j) fuse = conv_resblock_iter_supported(C, rb.c1[j].KW, c.rb_d[j]) && rb.c2[j].KW == rb.c1[j].KW;
+    if (fuse) {
+        // one launch per iteration (conv.h: ResIterDesc).  A workgroup reads its conv1 input WITH a halo and writes only its own
+        // rows, so the input of an iteration is never the buffer it writes: the bf16 streams alternate between the two slots of
+        // `xt`; the fp32 input of iteration 0 (read with a halo) goes to `work`, or to final_dst when x_in IS work.
+        const float* cur = x_in;
+        bf16_t* sin = nullptr;
+        for (int j = 0; j < N_DIL; ++j) {
+            const bool last = j == N_DIL - 1;
+            ResIterDesc r{};
+            r.x = j == 0 ? x_in : nullptr; r.x_act = sin; r.resid = cur; r.bs = bs; r.ld = C;
+            r.alpha1 = rb.a1[j]; r.alpha2 = rb.a2[j]; r.bias1 = rb.c1[j].bias; r.bias2 = rb.c2[j].bias;
+            r.KW = rb.c1[j].KW; r.dil = c.rb_d[j];
+            r.B = B; r.L = Lmax; r.C = C; r.len = len;
+            bf16_t* sout = (sin == a1) ? a2 : a1;
+            if (last) { r.y = final_dst; r.out_scale = final_scale; r.accumulate = final_acc; }
+            else {
+                r.y = (j == 0 && x_in == work) ? final_dst : work;
+                r.y_act = sout; r.alpha_out = rb.a1[j + 1]; r.out_scale = 1.f; r.accumulate = 0;
+            }
+            FY_TRY(conv_resblock_iter(r, rb.c1[j], rb.c2[j], st));
+            cur = r.y; sin = sout;
+        }
+        return FY_OK;
+    }
     for (int j = 0; j < N_DIL; ++j) {
         const float* cur = j == 0 ? x_in : work;
         ConvDesc d = base_desc(B);

@@ -37,3 +37,8 @@ python3 $R/tests/micro/pmc_aggregate.py /tmp/pmc_lm_FETCH_SIZE /tmp/pmc_lm_WRITE
 echo "[prof] LM decode PMC done"
 python3 $R/tests/micro/gemm_pmc.py
 cp $O/gemm_pmc.json $O/r02_gemm_pmc.json
+echo "[prof] GEMM PMC done"
+# 4. the vocoder alone at BASELINE.json configs[4] (32 x 10 000 frames): per-kernel times, and its traffic on the stand-alone driver
+bash $R/tests/micro/prof_hift.sh
+python3 $R/tests/micro/hift_pmc.py
+cp $O/hift_pmc.json $O/r02_hift_pmc.json
