@@ -256,3 +256,26 @@ np.savez({str(tmp_path / 'out.npz')!r}, plain=out[0], stream=out[1])
     for b, n in enumerate(lens):                          # rows past a sequence's length are not defined
         assert np.array_equal(here[0][b, :, :n], other["plain"][b, :, :n]), b
         assert np.array_equal(here[1][b, :, :n], other["stream"][b, :, :n]), b
+
+
+def test_bench_sized_estimator_equals_pairs():
+    """The benchmark's estimator call (16 sequences x 400 frames: M = 6400 rows) picks other kernels than the small calls the
+    oracle tests make - 320x256 GEMM tiles with staggered wave groups for qkv, 16x16x32-MFMA tilings for the rest, one attention
+    workgroup per (sequence, head).  Every tiling accumulates K in the same order and both attention forms walk the key tiles
+    alike, so the big call must reproduce, bit for bit, what the same sequences give two at a time."""
+    eng, _, _ = make(FlowCfg(), max_batch=8, max_frames=400)
+    T, B2 = 400, 16
+    g = lambda name, shape: torch.from_numpy(synth.normal(f"in.bigest.{name}", shape)).to(DEV)
+    x, mu, cond, spks = g("x", (B2, 80, T)), g("mu", (B2, 80, T)), g("cond", (B2, 80, T)), g("spks", (B2, 80))
+    t = torch.full((B2,), 0.3, device=DEV)
+    lens = [400, 400, 377, 400, 256, 400, 400, 129, 400, 400, 400, 31, 400, 400, 390, 400]
+    mask = torch.zeros(B2, 1, T, device=DEV)
+    for b, n in enumerate(lens):
+        mask[b, 0, :n] = 1
+    big = eng.estimator(x, mask, mu, t, spks, cond)
+    for b in range(0, B2, 2):
+        s = slice(b, b + 2)
+        pair = eng.estimator(x[s].contiguous(), mask[s].contiguous(), mu[s].contiguous(), t[s].contiguous(), spks[s].contiguous(), cond[s].contiguous())
+        for k in range(2):
+            n = lens[b + k]
+            assert torch.equal(big[b + k, :, :n], pair[k, :, :n]), b + k
