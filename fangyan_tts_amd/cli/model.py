@@ -285,11 +285,12 @@ class CosyVoice3Model:
                         raise RuntimeError("the language model emitted no speech token for an utterance")
                     with torch.cuda.stream(s_fv):
                         wav, samples = self._token2wav(inputs, out, n_tok, 1.0)
+                        t2 = time.perf_counter()
                         res = (wav if keep_on_device else wav.cpu())
                     s_fv.synchronize()
                     if trace:
-                        print(f"[pipe] batch {bi}: waited {1e3 * (t1 - t0):.1f} ms for ids, flow+vocoder {1e3 * (time.perf_counter() - t1):.1f} ms",
-                              file=sys.stderr)
+                        print(f"[pipe] batch {bi}: waited {1e3 * (t1 - t0):.1f} ms for ids, flow+vocoder {1e3 * (time.perf_counter() - t1):.1f} ms "
+                              f"(its launches were enqueued after {1e3 * (t2 - t1):.1f} ms)", file=sys.stderr)
                     # yielded OUTSIDE the stream context: the caller's own torch work (an all-gather, a copy) stays on its stream
                     yield res, samples, [out[b, : n_tok[b]] for b in range(len(inputs))]
             finally:
