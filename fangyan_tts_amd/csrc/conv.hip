@@ -536,7 +536,8 @@ int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_
 template <int WP, int WC, bool INB>
 __global__ __launch_bounds__(WP* WC * 64) void resblock_iter_k(ResIterDesc d, const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2) {
     constexpr int TP = WP * 64, C = WC * 64, NT = WP * WC * 64;
-    constexpr int ROWB = C * 2 + 16, NK = C / 16, N32 = C / 32, KH = NK / 2, EP = 68;
+    // input channels are walked in chunks of <= 128 (the order conv1d_bf16_mfma_k accumulates in): NCH chunks of NK 16-channel steps
+    constexpr int ROWB = C * 2 + 16, C16 = C / 16, NCH = C > 128 ? C / 128 : 1, NK = C16 / NCH, N32 = C / 32, KH = NK / 2, EP = 68;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: conv1's input rows X first; once every wave has read them, conv2's input rows Y [TP] take their place and the
     // epilogues park their tiles behind Y
@@ -618,20 +619,20 @@ __global__ __launch_bounds__(WP* WC * 64) void resblock_iter_k(ResIterDesc d, co
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        auto load_b = [&](int t, int half, frag_ab (&bb)[KH][2]) {
-            const bf16_t* wt = wp + (((long)t * NK + half * KH) * N32 + n32_base) * 512 + lane * 8;
+        auto load_b = [&](int ch, int t, int half, frag_ab (&bb)[KH][2]) {
+            const bf16_t* wt = wp + (((long)t * C16 + ch * NK + half * KH) * N32 + n32_base) * 512 + lane * 8;
 #pragma unroll
             for (int kk = 0; kk < KH; ++kk) {
                 bb[kk][0] = *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512);
                 bb[kk][1] = *reinterpret_cast<const frag_ab*>(wt + (long)kk * N32 * 512 + 512);
             }
         };
-        auto tap_half = [&](int t, int half, const frag_ab (&bb)[KH][2]) {
+        auto tap_half = [&](int ch, int t, int half, const frag_ab (&bb)[KH][2]) {
 #pragma unroll
             for (int kk = 0; kk < KH; ++kk) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
-                    const size_t off = (size_t)min(wpi * 64 + mi * 32 + lr + t * dil, last_row) * ROWB + ((half * KH + kk) * 16 + kh * 8) * 2;
+                    const size_t off = (size_t)min(wpi * 64 + mi * 32 + lr + t * dil, last_row) * ROWB + ((ch * NK + half * KH + kk) * 16 + kh * 8) * 2;
                     const frag_ab a = *reinterpret_cast<const frag_ab*>(src + off);
                     acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb[kk][0], acc[mi][0], 0, 0, 0);
                     acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb[kk][1], acc[mi][1], 0, 0, 0);
@@ -639,12 +640,14 @@ __global__ __launch_bounds__(WP* WC * 64) void resblock_iter_k(ResIterDesc d, co
             }
         };
         frag_ab h0[KH][2], h1[KH][2];
-        load_b(0, 0, h0);
-        for (int t = 0; t < d.KW; ++t) {
-            load_b(t, 1, h1);
-            tap_half(t, 0, h0);
-            if (t + 1 < d.KW) load_b(t + 1, 0, h0);
-            tap_half(t, 1, h1);
+        for (int ch = 0; ch < NCH; ++ch) {
+            load_b(ch, 0, 0, h0);
+            for (int t = 0; t < d.KW; ++t) {
+                load_b(ch, t, 1, h1);
+                tap_half(ch, t, 0, h0);
+                if (t + 1 < d.KW) load_b(ch, t + 1, 0, h0);
+                tap_half(ch, t, 1, h1);
+            }
         }
     };
     product(X, w1, d.dil, nrows - 1);
@@ -737,8 +740,12 @@ __global__ __launch_bounds__(WP* WC * 64) void resblock_iter_k(ResIterDesc d, co
 }
 
 bool conv_resblock_iter_supported(int C, int KW, int dil) {
-    if (C != 64 && C != 128) return false;
-    const int TP = C == 64 ? 256 : 128, h1 = (KW - 1) * dil, h2 = KW - 1;
+    if (C != 64 && C != 128 && C != 256) return false;
+    // 256 channels: a 64-row tile is what fits two workgroups per CU, and its halo (114 input rows and 64 conv1 rows for 54
+    // outputs) costs more than the fusion saves: 361 against 357 ms at BASELINE config 5 - built, bit-identical, off by default
+    static const bool fuse256 = getenv("FY_HIFT_FUSE256") && atoi(getenv("FY_HIFT_FUSE256")) != 0;
+    if (C == 256 && !fuse256) return false;
+    const int TP = C == 64 ? 256 : C == 128 ? 128 : 64, h1 = (KW - 1) * dil, h2 = KW - 1;
     return KW >= 1 && dil >= 1 && h2 < TP / 2 && (size_t)(TP + h1) * (C * 2 + 16) <= 80 * 1024;
 }
 
@@ -773,6 +780,7 @@ int conv_resblock_iter(const ResIterDesc& d, const ConvW& w1, const ConvW& w2, h
     FY_CHECK((((uintptr_t)d.x | (uintptr_t)d.x_act | (uintptr_t)d.resid | (uintptr_t)d.y | (uintptr_t)d.y_act) & 15) == 0, FY_ERR_ARG,
              "conv_resblock_iter: tensors must be 16-B aligned");
     if (d.C == 64) return d.x_act ? launch_resblock_iter<4, 1, true>(d, w1, w2, st) : launch_resblock_iter<4, 1, false>(d, w1, w2, st);
+    if (d.C == 256) return d.x_act ? launch_resblock_iter<1, 4, true>(d, w1, w2, st) : launch_resblock_iter<1, 4, false>(d, w1, w2, st);
     static const bool wide = getenv("FY_HIFT_FUSE_WIDE") && atoi(getenv("FY_HIFT_FUSE_WIDE"));      // experiment: 256-row tiles, one workgroup per CU
     if (wide) return d.x_act ? launch_resblock_iter<4, 2, true>(d, w1, w2, st) : launch_resblock_iter<4, 2, false>(d, w1, w2, st);
     return d.x_act ? launch_resblock_iter<2, 2, true>(d, w1, w2, st) : launch_resblock_iter<2, 2, false>(d, w1, w2, st);
