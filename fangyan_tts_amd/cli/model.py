@@ -47,13 +47,12 @@ class CosyVoice3Model:
         self.llms = [LlmEngine(llm_weights, cfg.llm, max_batch=max_batch * self.lm_group, max_ctx=2 + max_text + max_prompt_tokens + max_tokens,
                                device=self.device, keep_weights=keep_llm_weights and i == 0) for i in range(max(1, n_llm))]
         self.llm = self.llms[0]
-        # Several LM handles decoding beside the flow decoder (tts_pipeline) want the one-launch-per-operation decode: its
-        # short kernels interleave with the other streams, while the persistent step holds 152 CUs for its whole duration
-        # and two of them never overlap (measured at batch 8: 86.6 ms per pipelined step against 102).  A single handle
-        # (tts, tts_batch, stream=True) uses the persistent step: lowest latency.
-        if len(self.llms) > 1:
-            for e in self.llms:
-                e.set_decode_mode(False)
+        # LM handles decoding beside the flow decoder (tts_pipeline) use the one-launch-per-operation decode: its short
+        # kernels interleave with the other streams, while the persistent step holds 152 CUs for its whole duration
+        # (measured at batch 8: 86.6 ms per pipelined step against 102).  tts, tts_batch and stream=True use the persistent
+        # step for up to 8 sequences: lowest latency.
+        # tts_pipeline switches its LM handles to the per-operation path for its duration (below): a persistent grid needs
+        # 152 CUs to itself, which it never has beside the flow stream or on a CU-masked stream.
         self.flow = FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device)
         self.hift = HiftEngine(hift_weights, cfg.hift, max_batch=max_batch, max_frames=2 * max_tokens, device=self.device)
         # The reference lets several threads enter tts() on one model object (a gRPC pool, runtime/python/grpc/server.py:68-69;
@@ -71,6 +70,8 @@ class CosyVoice3Model:
         self._free = _q.Queue()
         for ln in self.lanes:
             self._free.put(ln)
+        # `model.llm.load_state_dict` (compare_inference.py:42 swaps a fine-tuned LM in) must reach every LM handle
+        self.llm._peers = [e for e in self.llms[1:]] + [ln.llm for ln in self.lanes[1:]]
         self._count_mu = threading.Lock()
         # The reference draws these buffers once at construction and never stores them in a checkpoint
         # (flow_matching.py:199-200; generator.py:223-226); pass them in to reproduce a given instance.
@@ -113,22 +114,57 @@ class CosyVoice3Model:
                 o += nb
             self.llms[i].set_sampler("ras", u)
 
+    def _acquire_lane(self):
+        """A free lane; waits while every lane is busy - unless THIS thread is what keeps them busy (a stream=True generator it
+        has not exhausted or closed), which would wait forever: that is an error, said so."""
+        import queue as _q
+        me = threading.get_ident()
+        holders = self.__dict__.setdefault("_lane_holders", {})
+        while True:
+            try:
+                ln = self._free.get(timeout=0.2)
+                break
+            except _q.Empty:
+                with self._count_mu:
+                    mine = sum(1 for h in holders.values() if h == me)
+                if mine == len(self.lanes):
+                    raise RuntimeError("every lane of this model is held by this thread (a tts(stream=True) generator that was neither "
+                                       "exhausted nor closed): finish or close() it first, or build the model with concurrency > 1")
+        with self._count_mu:
+            holders[id(ln)] = me
+        return ln
+
+    def _release_lane(self, ln):
+        with self._count_mu:
+            self.__dict__.setdefault("_lane_holders", {}).pop(id(ln), None)
+        self._free.put(ln)
+
+    def _lane_stream(self, ln):
+        """The lane's stream as the current stream for the engine calls inside (lanes after the first have their own)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            if ln.stream is None:
+                yield
+            else:
+                ln.stream.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(ln.stream):
+                    yield
+                ln.stream.synchronize()
+        return cm()
+
     def _take_lane(self):
         import contextlib
 
         @contextlib.contextmanager
         def cm():
-            ln = self._free.get()                              # waits while every lane is busy
+            ln = self._acquire_lane()
             try:
-                if ln.stream is None:
+                with self._lane_stream(ln):
                     yield ln
-                else:
-                    ln.stream.wait_stream(torch.cuda.current_stream(self.device))
-                    with torch.cuda.stream(ln.stream):
-                        yield ln
-                    ln.stream.synchronize()
             finally:
-                self._free.put(ln)
+                self._release_lane(ln)
         return cm()
 
     def _take_all_lanes(self):
@@ -136,12 +172,14 @@ class CosyVoice3Model:
 
         @contextlib.contextmanager
         def cm():
-            got = [self._free.get() for _ in self.lanes]      # the pipeline owns every handle while it runs
+            got = []
             try:
+                for _ in self.lanes:                           # the pipeline owns every handle while it runs
+                    got.append(self._acquire_lane())
                 yield
             finally:
                 for ln in got:
-                    self._free.put(ln)
+                    self._release_lane(ln)
         return cm()
 
     def _next_batch_ids(self, n: int = 1):
@@ -270,6 +308,9 @@ class CosyVoice3Model:
 
         threads = [th.Thread(target=producer, args=(i,), daemon=True) for i in range(n_prod)]
         with self._take_all_lanes():
+            was_persistent = [e.persistent for e in self.llms]
+            for e in self.llms:
+                e.set_decode_mode(False)
             box["base"] = self._next_batch_ids(len(batches))
             for t in threads:
                 t.start()
@@ -306,6 +347,8 @@ class CosyVoice3Model:
                             except queue.Empty:
                                 pass
                         t.join(timeout=0.05)
+                for e, p in zip(self.llms, was_persistent):
+                    e.set_decode_mode(p)
 
     def prepare_pipeline(self, flow_cu_exclude: Optional[int] = None):
         """Place the pipeline's streams now (otherwise the first tts_pipeline call does it, ~0.1-0.4 s)."""
@@ -393,8 +436,15 @@ class CosyVoice3Model:
         self.__dict__.pop("_masked_streams", None)
         self.__dict__.pop("_pipe_stream_sets", None)
 
-    def _token2wav(self, inputs, out, n_tok, speed, ln=None):
-        ln = ln or self.lanes[0]
+    def _prompt_tensors(self, inputs):
+        """The flow decoder's per-utterance prompt (tokens, mel, x-vector) padded into batch tensors ON THE DEVICE, built once
+        per set of prompt tensors (a serving loop and the benchmark present the same prompts again and again; keyed by the
+        tensors' identities and in-place version counters; the cache keeps the tensors alive)."""
+        cache = self.__dict__.setdefault("_prompt_cache", {})
+        key = tuple((id(t), t._version) for d in inputs for t in (d["flow_prompt_speech_token"], d["prompt_speech_feat"], d["flow_embedding"]))
+        hit = cache.get(key)
+        if hit is not None:
+            return hit[1]
         B = len(inputs)
         fp = [d["flow_prompt_speech_token"].reshape(-1) for d in inputs]
         pf = [d["prompt_speech_feat"].reshape(-1, 80) for d in inputs]
@@ -405,8 +455,18 @@ class CosyVoice3Model:
             ptok[b, : len(fp[b])] = fp[b].to(torch.int32)
             pfeat[b, : pf[b].shape[0]] = pf[b]
         emb = torch.cat([d["flow_embedding"].reshape(1, -1) for d in inputs]).float()
-        mel = ln.flow.inference(out, n_tok, ptok, [len(t) for t in fp], pfeat, [f.shape[0] for f in pf], emb, self.rand_noise,
-                                flags=self.flow_flags)
+        val = (ptok.to(self.device), [len(t) for t in fp], pfeat.to(self.device), [f.shape[0] for f in pf], emb.to(self.device))
+        torch.cuda.current_stream(self.device).synchronize()     # the copies are complete before another stream may use them
+        if len(cache) >= 16:
+            cache.pop(next(iter(cache)))
+        cache[key] = ([(d["flow_prompt_speech_token"], d["prompt_speech_feat"], d["flow_embedding"]) for d in inputs], val)
+        return val
+
+    def _token2wav(self, inputs, out, n_tok, speed, ln=None):
+        ln = ln or self.lanes[0]
+        B = len(inputs)
+        ptok, n_fp, pfeat, n_pf, emb = self._prompt_tensors(inputs)
+        mel = ln.flow.inference(out, n_tok, ptok, n_fp, pfeat, n_pf, emb, self.rand_noise, flags=self.flow_flags)
         frames = [2 * n for n in n_tok]
         if speed != 1.0:                                    # cli/model.py:435-437
             assert B == 1, "speed change only supports a single utterance"
@@ -441,14 +501,19 @@ class CosyVoice3Model:
         look, hop0 = self.cfg.flow.pre_lookahead, self.token_hop_len
         up = self.cfg.hift.upsample_total
         self._check_capacity([d], None)
-        with self._take_lane() as ln:
-            if source_tokens is None:
-                self._arm_lane_sampler(ln, self._next_batch_ids(), 1)
-                out, _, _ = ln.llm.begin(text, ptext, pspeech)
-                (n,), (done,) = ln.llm.step(0)
-            else:                                               # vc_job (cli/model.py:131-133): the token list is given, complete
-                out = source_tokens.reshape(1, -1).to(self.device, torch.int32)
-                n, done = out.shape[1], True
+        # The lane is held from the first chunk to the last (the LM handle carries the generation), but its stream is the
+        # current stream only INSIDE the engine calls: the consumer's own torch work between two chunks stays on the
+        # consumer's stream.  An abandoned generator releases the lane when it is closed or collected (GeneratorExit).
+        ln = self._acquire_lane()
+        try:
+            with self._lane_stream(ln):
+                if source_tokens is None:
+                    self._arm_lane_sampler(ln, self._next_batch_ids(), 1)
+                    out, _, _ = ln.llm.begin(text, ptext, pspeech)
+                    (n,), (done,) = ln.llm.step(0)
+                else:                                           # vc_job (cli/model.py:131-133): the token list is given, complete
+                    out = source_tokens.reshape(1, -1).to(self.device, torch.int32)
+                    n, done = out.shape[1], True
             pad = -(-n_fp // hop0) * hop0 - n_fp
             offset, speech_offset, mel_all = 0, 0, None
 
@@ -460,22 +525,26 @@ class CosyVoice3Model:
                 mel_all = mel if mel_all is None else torch.cat([mel_all, mel], dim=2)
                 wav, _ = ln.hift.inference(mel_all.contiguous(), self.rand_ini, self.sine_noise, finalize=finalize, flags=self.hift_flags)
                 end = up * (mel_all.shape[2] if finalize else mel_all.shape[2] - 8)
-                return wav[:, speech_offset:end], mel_all, end
+                return wav[:, speech_offset:end].cpu(), mel_all, end
 
             while True:
                 need = offset + (hop0 + pad if offset == 0 else hop0) + look
-                while n < need and not done:                # the silent-token filter may drop tokens: ask again until enough
-                    (n,), (done,) = ln.llm.step(need - n)
-                if n < need:
-                    break
-                wav, mel_all, speech_offset = token2wav(need, offset, mel_all, speech_offset, True, False)
+                with self._lane_stream(ln):
+                    while n < need and not done:            # the silent-token filter may drop tokens: ask again until enough
+                        (n,), (done,) = ln.llm.step(need - n)
+                    if n < need:
+                        break
+                    wav, mel_all, speech_offset = token2wav(need, offset, mel_all, speech_offset, True, False)
                 offset = need - look
-                yield {"tts_speech": wav.cpu()}
+                yield {"tts_speech": wav}
             if n < 1:
                 raise RuntimeError("the language model emitted no speech token for an utterance")
-            wav, mel_all, speech_offset = token2wav(n, offset, mel_all, speech_offset, False, True)
+            with self._lane_stream(ln):
+                wav, mel_all, speech_offset = token2wav(n, offset, mel_all, speech_offset, False, True)
             self.last_mel, self.last_frames = mel_all, [mel_all.shape[2]]
-            yield {"tts_speech": wav.cpu()}
+            yield {"tts_speech": wav}
+        finally:
+            self._release_lane(ln)
 
     # ------------------------------------------------------------------ reference-shaped path
     def tts(self, text=torch.zeros(1, 0, dtype=torch.int32), flow_embedding=torch.zeros(0, 192), llm_embedding=torch.zeros(0, 192),

@@ -12,4 +12,4 @@ int llm_attention(const float* q, int q_ld, const float* Kc, const float* Vc, co
 
 // decode step: RoPE of q / new k, cache append and attention over 0..row_pos[r] in one launch (qkv raw, fp32)
 int llm_attention_step(const float* qkv, float* Kc, float* Vc, const int* row_seq, const int* row_pos, const float* inv_freq,
-                       float* out, int o_ld, int R, int Hq, int Hk, int max_ctx, hipStream_t st);
+                       float* out, int o_ld, int R, int Hq, int Hk, int max_ctx, hipStream_t st, bf16_t* img = nullptr);

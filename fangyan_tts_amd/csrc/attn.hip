@@ -7,6 +7,7 @@
 //                     (query row, query head); serves prefill rows and decode steps alike
 //                     (transformers Qwen2Attention as called from llm/llm.py:246-258).
 #include "attn.h"
+#include "gemv32.h"
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
@@ -296,7 +297,7 @@ int llm_attention(const float* q, int q_ld, const float* Kc, const float* Vc, co
 __global__ __launch_bounds__(256) void llm_attention_step_k(const float* __restrict__ qkv, float* __restrict__ Kc, float* __restrict__ Vc,
                                                             const int* __restrict__ row_seq, const int* __restrict__ row_pos,
                                                             const float* __restrict__ inv_freq, float* __restrict__ out, int o_ld,
-                                                            int Hq, int Hk, int max_ctx, float scale) {
+                                                            int Hq, int Hk, int max_ctx, float scale, bf16_t* __restrict__ img) {
     // 4 waves per (row, query head): every wave rotates q / the new k itself (64 lanes = 64 dims); the cached keys
     // are spread one per thread, the value rows in four contiguous quarters, partial sums meet in LDS.
     extern __shared__ float sh[];             // [64] q + [max_ctx] scores + [4][64] partial outputs + [8] reductions
@@ -376,17 +377,30 @@ __global__ __launch_bounds__(256) void llm_attention_step_k(const float* __restr
     __syncthreads();
     if (wid == 0) {
         float o = ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane])) + p_new * vv;
-        out[(long)r * o_ld + hq * 64 + lane] = o / sum;
+        o /= sum;
+        if (!img) { out[(long)r * o_ld + hq * 64 + lane] = o; return; }
+        // the o-proj product of the 32-row path reads an A image (gemv32.h): the exact 3-way bf16 split of this head's 64
+        // values as 8 pieces of 16 bytes per plane; lanes 0-23 each assemble and store one
+        unsigned h, m, l;
+        gv32_split3(o, h, m, l);
+        bf16_t* ps = reinterpret_cast<bf16_t*>(part);           // every lane has read its partial sums above (one wave, in order)
+        ps[lane] = (bf16_t)h; ps[64 + lane] = (bf16_t)m; ps[128 + lane] = (bf16_t)l;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < 24) {
+            const int plane = lane >> 3, pc = lane & 7, col0 = hq * 64 + 8 * pc;
+            const uint4 piece = *reinterpret_cast<const uint4*>(ps + plane * 64 + pc * 8);
+            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(img) + gv32_off(Hq * 4, r, col0, plane)) = piece;
+        }
     }
 }
 
 int llm_attention_step(const float* qkv, float* Kc, float* Vc, const int* row_seq, const int* row_pos, const float* inv_freq,
-                       float* out, int o_ld, int R, int Hq, int Hk, int max_ctx, hipStream_t st) {
-    FY_CHECK(qkv && Kc && Vc && row_seq && row_pos && inv_freq && out && R >= 1 && Hq % Hk == 0, FY_ERR_ARG, "llm_attention_step: bad arguments");
+                       float* out, int o_ld, int R, int Hq, int Hk, int max_ctx, hipStream_t st, bf16_t* img) {
+    FY_CHECK(qkv && Kc && Vc && row_seq && row_pos && inv_freq && (out || img) && R >= 1 && Hq % Hk == 0, FY_ERR_ARG, "llm_attention_step: bad arguments");
     size_t lds = (64 + (size_t)max_ctx + 256 + 8) * sizeof(float);
     FY_CHECK(lds <= 64 * 1024, FY_ERR_ARG, "llm_attention_step: context %d too long for the score buffer", max_ctx);
     hipLaunchKernelGGL(llm_attention_step_k, dim3(R, Hq), dim3(256), lds, st, qkv, Kc, Vc, row_seq, row_pos, inv_freq, out, o_ld, Hq, Hk,
-                       max_ctx, 0.125f);
+                       max_ctx, 0.125f, img);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }

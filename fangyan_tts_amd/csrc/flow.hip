@@ -423,11 +423,14 @@ extern "C" void fy_flow_destroy(fy_flow* f) { delete f; }
 
 // fp32 operand buffers of the fp32-class mode, sized for the handle's capacity, on first use
 static int ensure_precise(fy_flow* f) {
-    if (f->xn32) return FY_OK;
     const fy_flow_config& c = f->cfg;
     const size_t M = (size_t)2 * f->max_batch * f->Tmax, D = c.dim, inner = (size_t)c.heads * c.head_dim, FF = D * c.ff_mult;
-    FY_TRY(f->pool.alloc(&f->a_in32, M * 4 * c.mel)); FY_TRY(f->pool.alloc(&f->qkv32, M * 3 * inner));
-    FY_TRY(f->pool.alloc(&f->ao32, M * inner)); FY_TRY(f->pool.alloc(&f->ff32, M * FF)); FY_TRY(f->pool.alloc(&f->xn32, M * D));
+    // buffer by buffer, so a call after a partial failure (out of memory) allocates only what is still missing
+    if (!f->a_in32) FY_TRY(f->pool.alloc(&f->a_in32, M * 4 * c.mel));
+    if (!f->qkv32) FY_TRY(f->pool.alloc(&f->qkv32, M * 3 * inner));
+    if (!f->ao32) FY_TRY(f->pool.alloc(&f->ao32, M * inner));
+    if (!f->ff32) FY_TRY(f->pool.alloc(&f->ff32, M * FF));
+    if (!f->xn32) FY_TRY(f->pool.alloc(&f->xn32, M * D));
     return FY_OK;
 }
 
@@ -471,8 +474,19 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
         q.rope = f->rope; q.rope_T = Tmax; q.rope_half = c.head_dim / 2; q.rope_stride = inner;
         if (pr) {
             FY_TRY(gemm_f32a_precise(f->xn32, D, k.wqkv, M, 3 * inner, D, q, st));
-            hipLaunchKernelGGL(dit_attention_f32_k, dim3(cdiv(Tmax, 4), c.heads, nseq), dim3(256), (size_t)4 * (64 + Tmax) * sizeof(float), st,
-                               f->qkv32, f->ao32, f->seq_len, Tmax, c.heads, streaming ? c.static_chunk : 0);
+            {
+                // the score rows live in LDS: 16 (64 + Tmax) bytes per workgroup, above the 64 KB default from ~4000 frames on
+                const size_t at_lds = (size_t)4 * (64 + Tmax) * sizeof(float);
+                FY_CHECK(at_lds <= (size_t)160 * 1024, FY_ERR_ARG, "fy_flow (FY_PRECISE): %d frames exceed the fp32 attention's score buffer (10176 frames)", Tmax);
+                static size_t at_lds_set = 0;
+                if (at_lds > at_lds_set) {
+                    HIP_TRY(hipFuncSetAttribute((const void*)dit_attention_f32_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)at_lds));
+                    at_lds_set = at_lds;
+                }
+                hipLaunchKernelGGL(dit_attention_f32_k, dim3(cdiv(Tmax, 4), c.heads, nseq), dim3(256), at_lds, st,
+                                   f->qkv32, f->ao32, f->seq_len, Tmax, c.heads, streaming ? c.static_chunk : 0);
+                HIP_TRY(hipGetLastError());
+            }
         } else {
             FY_TRY(gemm_bf16(f->xn, D, k.wqkv, M, 3 * inner, D, q, st));
             FY_TRY(dit_attention(f->qkv, f->ao, f->seq_len, nseq, Tmax, c.heads, streaming ? c.static_chunk : 0, st));

@@ -10,6 +10,7 @@
 // per-sequence state (positions, counts, stop flags) on the device, so a step needs no host sync.
 #include "attn.h"
 #include "gemm.h"
+#include "gemv32.h"
 #include "llm_decode.h"
 #include "runtime.h"
 #include <algorithm>
@@ -50,6 +51,12 @@ struct fy_llm {
     int prefill_gemm_rows = 320;           // FY_LLM_PREFILL_GEMM_ROWS: from this many prefill rows on, the tiled GEMMs
     bool prefill_gemm = true;              // FY_LLM_PREFILL_GEMM=0 keeps the 8-row products for the prefill too (A/B measurements)
     int decode_mode = 1;                   // fy_llm_set_decode_mode: 1 = use it, 0 = one launch per operation
+    // per-operation products that serve 32 rows per weight pass (gemv32.h; FY_LLM_GEMV32=0 keeps the 8-row products of gemm.h):
+    // the operands travel as A images written by the producers' epilogues
+    bool gv32 = true;
+    bf16_t *img_h = nullptr, *img_ao = nullptr, *img_act = nullptr;
+    float *ssq = nullptr, *part32 = nullptr;
+    int *cnt32 = nullptr;
     int n_speech() const { return cfg.speech_tokens + 200; }
     int qkv_dim() const { return (cfg.q_heads + 2 * cfg.kv_heads) * cfg.head_dim; }
     size_t cache_layer() const { return (size_t)max_batch * cfg.kv_heads * max_ctx * cfg.head_dim; }
@@ -114,11 +121,30 @@ __global__ void gather_rows_k(const float* __restrict__ src, const int* __restri
     for (int c = threadIdx.x; c < H; c += blockDim.x) dst[(long)b * H + c] = src[(long)idx[b] * H + c];
 }
 
+// What the 32-row decode path (gemv32.h) needs of the sampler besides the next input embedding h[b] = speech_embedding[id]:
+// that row's A image under layer 0's input norm weight and its per-tile sums of squares (null img: nothing).
+struct NextImg {
+    bf16_t* img = nullptr;
+    float* ssq = nullptr;
+    const float* ln = nullptr;
+    int Rpad = 0;
+};
+__device__ __forceinline__ void next_image(const NextImg& ni, const float* __restrict__ e, int b, int H, int tid) {
+    if (!ni.img) return;
+    for (int c0 = tid * 4; c0 < H; c0 += 1024) {             // 8 consecutive threads = one 32-column tile
+        const float4 v = *reinterpret_cast<const float4*>(e + c0), w = *reinterpret_cast<const float4*>(ni.ln + c0);
+        gv32_put4(ni.img, H / 16, b, c0, v.x * w.x, v.y * w.y, v.z * w.z, v.w * w.w);
+        float q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+        if ((tid & 7) == 0) ni.ssq[(long)(c0 >> 5) * ni.Rpad + b] = q;
+    }
+}
+
 // log_softmax + greedy rule + stop / silent-token bookkeeping + next input embedding.
 // st rows: 0 pos, 1 raw_n, 2 n_out, 3 done, 4 silent run, 5 min_len, 6 max_len.
 __global__ __launch_bounds__(256) void sample_k(const float* __restrict__ logits, int n_all, int n_real, int* __restrict__ st, int mb,
                                                 int* __restrict__ out_ids, int out_ld, const float* __restrict__ semb,
-                                                float* __restrict__ h, int H, float* __restrict__ logp_keep, int keep_step) {
+                                                float* __restrict__ h, int H, float* __restrict__ logp_keep, int keep_step, NextImg ni) {
     __shared__ float sv[256];
     __shared__ int si[256];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -176,6 +202,7 @@ __global__ __launch_bounds__(256) void sample_k(const float* __restrict__ logits
         return;
     }
     for (int c = tid; c < H; c += 256) h[(long)b * H + c] = semb[(long)id * H + c];      // llm.py:525
+    next_image(ni, semb + (long)id * H, b, H, tid);
     if (tid == 0) {
         int run = st[4 * mb + b];
         bool silent = false;
@@ -213,7 +240,7 @@ __global__ __launch_bounds__(256) void sample_ras_k(const float* __restrict__ lo
                                                     int* __restrict__ out_ids, int out_ld, const float* __restrict__ semb,
                                                     float* __restrict__ h, int H, float* __restrict__ logp_keep, int keep_step,
                                                     const float* __restrict__ uni, long n_uni, int* __restrict__ recent,
-                                                    int top_k, float top_p, int win, float rep_thr) {
+                                                    int top_k, float top_p, int win, float rep_thr, NextImg ni) {
     extern __shared__ float pl[];                            // softmax(logp) in index order
     __shared__ float sv[256];
     __shared__ int si[256];
@@ -370,6 +397,7 @@ __global__ __launch_bounds__(256) void sample_ras_k(const float* __restrict__ lo
         return;
     }
     for (int c = tid; c < H; c += 256) h[(long)b * H + c] = semb[(long)id * H + c];      // llm.py:525
+    next_image(ni, semb + (long)id * H, b, H, tid);
     if (tid == 0) {
         recent[(raw_n % win) * mb + b] = id;                                   // decoded_tokens[-win_size:], order does not matter
         int run = st[4 * mb + b];
@@ -526,7 +554,24 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
     }
     const size_t R = l->max_rows, B = max_batch;
     TRYC(l->pool.alloc(&l->h, R * H)); TRYC(l->pool.alloc(&l->xn, R * H)); TRYC(l->pool.alloc(&l->qkv, R * l->qkv_dim()));
-    TRYC(l->pool.alloc(&l->ao, R * H)); TRYC(l->pool.alloc(&l->act, (size_t)16)); TRYC(l->pool.alloc(&l->act_split, ((R + 7) / 8) * 24 * (size_t)I)); TRYC(l->pool.alloc(&l->hb, B * H));
+    TRYC(l->pool.alloc(&l->ao, R * H)); TRYC(l->pool.alloc(&l->act, (size_t)16)); TRYC(l->pool.alloc(&l->hb, B * H));
+    if (const char* e = getenv("FY_LLM_GEMV32")) l->gv32 = atoi(e) != 0;
+    if (H % 32 != 0 || I % 16 != 0 || H / 32 > 32) l->gv32 = false;
+    // rows the 8- / 32-row products ever see: the tiled GEMMs take a prefill from prefill_gemm_rows on (when they apply at all)
+    const size_t Rg = (l->prefill_gemm && H % 64 == 0 && I % 64 == 0) ? std::min<size_t>(R, std::max<size_t>(B, (size_t)l->prefill_gemm_rows)) : R;
+    if (l->gv32) {
+        const size_t n_h = gv32_image_elems((int)Rg, H), n_a = gv32_image_elems((int)Rg, I), n_s = gv32_ssq_floats((int)Rg, H);
+        TRYC(l->pool.alloc(&l->img_h, n_h)); TRYC(l->pool.alloc(&l->img_ao, n_h)); TRYC(l->pool.alloc(&l->img_act, n_a));
+        TRYC(l->pool.alloc(&l->ssq, n_s));
+        TRYC(l->pool.alloc(&l->part32, gv32_partial_floats((int)Rg, H, I) + 16)); TRYC(l->pool.alloc(&l->cnt32, gv32_counter_ints((int)Rg, H, I) + 16));
+        // rows beyond the live ones are never written and must read as zeros (a row of the A operand only reaches its own outputs)
+        if (hipMemsetAsync(l->img_h, 0, n_h * 2, st) != hipSuccess || hipMemsetAsync(l->img_ao, 0, n_h * 2, st) != hipSuccess ||
+            hipMemsetAsync(l->img_act, 0, n_a * 2, st) != hipSuccess || hipMemsetAsync(l->ssq, 0, n_s * 4, st) != hipSuccess ||
+            hipMemsetAsync(l->cnt32, 0, (gv32_counter_ints((int)Rg, H, I) + 16) * sizeof(int), st) != hipSuccess) {
+            fy_set_error("fy_llm_create: memset failed");
+            return fail(FY_ERR_HIP);
+        }
+    } else TRYC(l->pool.alloc(&l->act_split, ((R + 7) / 8) * 24 * (size_t)I));
     TRYC(l->pool.alloc(&l->logits, B * NS)); TRYC(l->pool.alloc(&l->partial, gemv_partial_floats((int)R, H, I) + 16));
     TRYC(l->pool.alloc(&l->counters, gemv_counter_ints((int)R, H, I) + 16));
     if (hipMemsetAsync(l->counters, 0, (gemv_counter_ints((int)R, H, I) + 16) * sizeof(int), st) != hipSuccess) { fy_set_error("fy_llm_create: memset failed"); return fail(FY_ERR_HIP); }
@@ -558,6 +603,10 @@ extern "C" void fy_llm_destroy(fy_llm* l) {
 }
 
 // ---- forward over R rows (prefill rows or one decode row per sequence) ---------------------------------------------
+static bool llm_prefill_by_gemm(const fy_llm* l, int R) {
+    return R >= l->prefill_gemm_rows && l->cfg.hidden % 64 == 0 && l->cfg.inter % 64 == 0 && l->prefill_gemm;
+}
+
 static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, bool decode, hipStream_t st) {
     const fy_llm_config& c = l->cfg;
     const int H = c.hidden, I = c.inter, QKV = l->qkv_dim();
@@ -565,7 +614,7 @@ static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, 
     // fidelity as the 8-row products below, which at R rows would stream every weight matrix ceil(R / 8) times.
     // Measured (tests/prefill_probe.py, CosyVoice3-0.5B): 4 x 296 rows 14.9 ms against 42.8; 8 x ~25 rows 10.0 against 7.1 (a
     // handful of 128-row tiles leaves the chip empty) - the crossover is near 300 rows.
-    const bool gemm_path = !decode && R >= l->prefill_gemm_rows && H % 64 == 0 && I % 64 == 0 && l->prefill_gemm;
+    const bool gemm_path = !decode && llm_prefill_by_gemm(l, R);
     for (int i = 0; i < c.layers; ++i) {
         const LlmLayerW& k = l->L[i];
         float* Kc = l->Kc + (size_t)i * l->cache_layer();
@@ -588,6 +637,36 @@ static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, 
             GemmEpi d;
             d.mode = EPI_GATE_RESID; d.resid = l->h; d.gate = l->ones; d.ldc = H;
             FY_TRY(gemm_f32a_exact(l->actf, I, k.rd, R, H, I, d, st));
+            continue;
+        }
+        if (l->gv32) {
+            // 32 rows per weight pass; the caller left the A image of (ln1 x h) and its sums of squares (prefill: gv32_split_rows,
+            // decode: the sampler), every product's epilogue leaves what the next one reads
+            const int NP = H / 32;
+            Gv32Args q;
+            q.W = k.wqkv; q.img = l->img_h; q.R = R; q.N = QKV; q.K = H; q.ssq = l->ssq; q.n_ssq = NP; q.eps = c.rms_eps; q.bias = k.bqkv;
+            q.y = l->qkv; q.ldy = QKV;
+            FY_TRY(gemv32(q, st));
+            if (decode) {
+                FY_TRY(llm_attention_step(l->qkv, Kc, Vc, row_seq, row_pos, l->inv_freq, nullptr, H, R, c.q_heads, c.kv_heads, l->max_ctx, st, l->img_ao));
+            } else {
+                hipLaunchKernelGGL(rope_kv_k, dim3(R), dim3(256), 0, st, l->qkv, Kc, Vc, row_seq, row_pos, l->inv_freq, c.q_heads, c.kv_heads, l->max_ctx);
+                FY_TRY(llm_attention(l->qkv, QKV, Kc, Vc, row_seq, row_pos, l->ao, H, R, c.q_heads, c.kv_heads, l->max_ctx, st));
+                FY_TRY(gv32_split_rows(l->ao, H, R, H, nullptr, l->img_ao, nullptr, st));
+            }
+            Gv32Args o;
+            o.W = k.wo; o.img = l->img_ao; o.R = R; o.N = H; o.K = H; o.mode = GV32_ADD_IMG; o.y = l->h; o.ldy = H;
+            o.ln_next = k.ln2; o.img_out = l->img_h; o.ssq_out = l->ssq;
+            FY_TRY(gemv32(o, st));
+            Gv32Args g;
+            g.W = k.wgu; g.img = l->img_h; g.R = R; g.N = 2 * I; g.K = H; g.ssq = l->ssq; g.n_ssq = NP; g.eps = c.rms_eps;
+            g.mode = GV32_SWIGLU_IMG; g.img_out = l->img_act;
+            FY_TRY(gemv32(g, st));
+            Gv32Args d;
+            d.W = k.wd; d.img = l->img_act; d.R = R; d.N = H; d.K = I; d.mode = GV32_ADD_IMG; d.y = l->h; d.ldy = H;
+            d.ln_next = i + 1 < c.layers ? l->L[i + 1].ln1 : l->norm_w; d.img_out = l->img_h; d.ssq_out = l->ssq;
+            d.partial = l->part32; d.counters = l->cnt32;
+            FY_TRY(gemv32(d, st));
             continue;
         }
         GemvArgs a;          // input RMSNorm fused into the projection
@@ -618,9 +697,18 @@ static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, 
 }
 
 static int llm_sample(fy_llm* l, int B, int32_t* out_ids, int out_ld, int keep_step, hipStream_t st);
-static int llm_head_and_sample(fy_llm* l, int B, const float* rows, int32_t* out_ids, int out_ld, int keep_step, hipStream_t st) {
+// have_img: the A image of (norm.weight x rows) and its sums of squares already stand in img_h / ssq (the last layer's down
+// projection left them: a decode step on the 32-row path)
+static int llm_head_and_sample(fy_llm* l, int B, const float* rows, int32_t* out_ids, int out_ld, int keep_step, hipStream_t st, bool have_img = false) {
     const fy_llm_config& c = l->cfg;
     const int H = c.hidden, NS = l->n_speech();
+    if (l->gv32) {
+        if (!have_img) FY_TRY(gv32_split_rows(rows, H, B, H, l->norm_w, l->img_h, l->ssq, st));
+        Gv32Args a;
+        a.W = l->w_head; a.img = l->img_h; a.R = B; a.N = NS; a.K = H; a.ssq = l->ssq; a.n_ssq = H / 32; a.eps = c.rms_eps; a.y = l->logits; a.ldy = NS;
+        FY_TRY(gemv32(a, st));
+        return llm_sample(l, B, out_ids, out_ld, keep_step, st);
+    }
     GemvArgs a;              // final RMSNorm fused into the llm_decoder product
     a.W = l->w_head; a.x = rows; a.ldx = H; a.R = B; a.N = NS; a.K = H; a.y = l->logits; a.ldy = NS;
     a.norm_w = l->norm_w; a.eps = c.rms_eps;
@@ -633,13 +721,15 @@ static int llm_sample(fy_llm* l, int B, int32_t* out_ids, int out_ld, int keep_s
     const fy_llm_config& c = l->cfg;
     const int H = c.hidden, NS = l->n_speech();
     FY_CHECK(NS <= 256 * 32, FY_ERR_ARG, "sample: %d logits exceed the kernel's register tile", NS);
+    NextImg ni;              // the next decode step's first operand (32-row path): image of ln1[0] x speech_embedding[id]
+    if (l->gv32) { ni.img = l->img_h; ni.ssq = l->ssq; ni.ln = l->L[0].ln1; ni.Rpad = 32 * cdiv(B, 32); }
     if (l->sampler == 1)
         hipLaunchKernelGGL(sample_ras_k, dim3(B), dim3(256), (size_t)NS * sizeof(float), st, l->logits, NS, c.speech_tokens, l->st, l->max_batch,
                            out_ids, out_ld, l->speech_emb, l->h, H, l->logp_keep, keep_step < FY_LLM_KEEP_LOGP ? keep_step : -1,
-                           l->uniforms, l->n_uniforms, l->recent, l->top_k, l->top_p, l->win_size, l->rep_thr);
+                           l->uniforms, l->n_uniforms, l->recent, l->top_k, l->top_p, l->win_size, l->rep_thr, ni);
     else
         hipLaunchKernelGGL(sample_k, dim3(B), dim3(256), 0, st, l->logits, NS, c.speech_tokens, l->st, l->max_batch, out_ids, out_ld,
-                           l->speech_emb, l->h, H, l->logp_keep, keep_step < FY_LLM_KEEP_LOGP ? keep_step : -1);
+                           l->speech_emb, l->h, H, l->logp_keep, keep_step < FY_LLM_KEEP_LOGP ? keep_step : -1, ni);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -697,6 +787,7 @@ extern "C" int fy_llm_begin(fy_llm* l, const int32_t* text_ids, const int32_t* n
     l->B = B;
     // prefill
     hipLaunchKernelGGL(embed_rows_k, dim3(R), dim3(256), 0, st, l->row_src, l->embed_tokens, l->speech_emb, l->h, H);
+    if (l->gv32 && !llm_prefill_by_gemm(l, R)) FY_TRY(gv32_split_rows(l->h, H, R, H, l->L[0].ln1, l->img_h, l->ssq, st));
     FY_TRY(llm_layers(l, R, l->row_seq, l->row_pos, false, st));
     hipLaunchKernelGGL(gather_rows_k, dim3(B), dim3(256), 0, st, l->h, l->last_row, l->hb, H);
     FY_TRY(llm_head_and_sample(l, B, l->hb, out_ids, out_ld, 0, st));
@@ -714,23 +805,29 @@ extern "C" int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t
     const int end = l->all_done ? l->step_next : (int)std::min<long>((long)l->step_next + n_steps, l->steps_cap);
     std::vector<int> done(mb, 0);
     unsigned dec_status = 0;
-    auto read_done = [&]() -> int {
-        HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
-        if (l->dec) FY_TRY(decode_status(l->dec, &dec_status, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        FY_CHECK(dec_status == 0, FY_ERR_STATE, "fy_llm_step: the decode kernel's grid hand-off timed out (its workgroups were not all resident: "
-                 "another persistent grid on the device?); set FY_LLM_PERSISTENT=0 to use the multi-launch path");
-        return FY_OK;
-    };
     int step = l->step_next;
     const bool persistent = l->dec && l->decode_mode == 1 && B <= 8;
+    auto read_done = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
+        // only a call that used the persistent step looks at (and clears) its time-out word: a time-out is reported once,
+        // and the handle then works on the per-operation path (fy_llm_set_decode_mode(0)) as the message says
+        if (persistent) FY_TRY(decode_status(l->dec, &dec_status, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (dec_status != 0) {
+            l->step_next = 0;                // the generation is void: no further steps are launched on it
+            FY_CHECK(false, FY_ERR_STATE, "fy_llm_step: the decode kernel's grid hand-off timed out (its workgroups were not all resident: "
+                     "another persistent grid on the device, or a CU-masked stream?); call fy_llm_set_decode_mode(handle, 0) or set "
+                     "FY_LLM_PERSISTENT=0 to use the multi-launch path, then start the generation again");
+        }
+        return FY_OK;
+    };
     for (; step < end; ++step) {
         if (persistent) {                    // the 24 layers + llm_decoder of the step in one launch, then the sampler
             FY_TRY(decode_step(l->dec, B, l->h, l->st, l->inv_freq, l->logits, st));
             FY_TRY(llm_sample(l, B, out_ids, out_ld, step, st));
         } else {
             FY_TRY(llm_layers(l, B, l->seq_ids, l->st, true, st));
-            FY_TRY(llm_head_and_sample(l, B, l->h, out_ids, out_ld, step, st));
+            FY_TRY(llm_head_and_sample(l, B, l->h, out_ids, out_ld, step, st, l->gv32));
         }
         if ((step & 7) == 7) {
             FY_TRY(read_done());

@@ -34,6 +34,7 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 #define SC1 16
+#define DEC_GO_WORD 32                     // the "go" word sits this many words behind the flag array (decode_create sizes and clears it)
 #define PER_MAX 10                         // partials per summing group in the reduction phase: G <= 16 * PER_MAX workgroups
 #define LDSP(p) ((__attribute__((address_space(3))) void*)(p))
 #define RLX __ATOMIC_RELAXED
@@ -356,7 +357,7 @@ __device__ __forceinline__ void sbar(volatile __attribute__((address_space(3))) 
 // at 152 workgroups).  Bounded by the real-time clock; false = timed out.
 __device__ __forceinline__ bool grid_sync(const DecArgs& a, const SCtx& c, unsigned epoch) {
     if (c.lane == 0) __hip_atomic_store(a.flags + c.g, epoch, RLX, AGT);
-    unsigned* go = a.flags + ((c.G + 3) / 4) * 4 + 32;     // a line of its own
+    unsigned* go = a.flags + ((c.G + 3) / 4) * 4 + DEC_GO_WORD;     // a line of its own
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     if (c.g != 0) {
         for (;;) {
@@ -810,11 +811,14 @@ __global__ __launch_bounds__(512, 2) void llm_decode_k(const DecArgs a) {
     extern __shared__ __attribute__((aligned(16))) char dec_smem[];
     const int tid = threadIdx.x, wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = blockIdx.x;
     if (tid == 0) {
-        *(volatile __attribute__((address_space(3))) int*)(dec_smem + C::OFF_MISC + 32) = 0;       // fail flag
+        // a time-out of an earlier launch that nobody has read yet (fy_llm_step looks every 8 steps): leave at once instead
+        // of waiting out the spin bound again
+        *(volatile __attribute__((address_space(3))) int*)(dec_smem + C::OFF_MISC + 32) = __hip_atomic_load(a.status, RLX, AGT) != 0;       // fail flag
         *(volatile __attribute__((address_space(3))) int*)(dec_smem + C::OFF_MISC + 36) = 0;       // S-wave barrier counter
         *(volatile __attribute__((address_space(3))) int*)(dec_smem + C::OFF_MISC + 40) = 0;       // layers whose partial sums have drained
     }
     __syncthreads();
+    if (*(volatile __attribute__((address_space(3))) int*)(dec_smem + C::OFF_MISC + 32)) return;
     if (wid < 4) w_main<C>(a, dec_smem, g, wid, lane);
     else s_main<C>(a, dec_smem, g, wid - 4, lane);
 }
@@ -904,9 +908,12 @@ int decode_create(DecodePlan** out, const DecodeShape& s, hipStream_t st) {
     TRYP(p->pool.alloc(&p->img_h, (size_t)IMG / 2)); TRYP(p->pool.alloc(&p->img_ao, (size_t)IMG / 2));
     TRYP(p->pool.alloc(&p->ssq_u, (size_t)(s.H / 8) * 8)); TRYP(p->pool.alloc(&p->ssq_o, (size_t)p->NTO * 8));
     TRYP(p->pool.alloc(&p->qkv, (size_t)8 * s.qkv())); TRYP(p->pool.alloc(&p->part, (size_t)p->G * 8 * s.H));
-    TRYP(p->pool.alloc(&p->flags, (size_t)((p->G + 3) / 4) * 4 + 4)); TRYP(p->pool.alloc(&p->status, (size_t)4));
+    // the flag words (G rounded up to a 16-byte load) and, a line further on, the "go" word grid_sync polls: all of it zeroed
+    // (hipMalloc does not clear, and a stale "go" of a destroyed plan would let every workgroup run through its hand-offs)
+    const size_t n_flag_words = (size_t)((p->G + 3) / 4) * 4 + DEC_GO_WORD + 4;
+    TRYP(p->pool.alloc(&p->flags, n_flag_words)); TRYP(p->pool.alloc(&p->status, (size_t)4));
 #undef TRYP
-    if (hipMemsetAsync(p->flags, 0, (((p->G + 3) / 4) * 4 + 4) * 4, st) != hipSuccess || hipMemsetAsync(p->status, 0, 16, st) != hipSuccess ||
+    if (hipMemsetAsync(p->flags, 0, n_flag_words * 4, st) != hipSuccess || hipMemsetAsync(p->status, 0, 16, st) != hipSuccess ||
         hipMemsetAsync(p->img_h, 0, IMG, st) != hipSuccess || hipMemsetAsync(p->img_ao, 0, IMG, st) != hipSuccess ||
         hipMemsetAsync(p->part, 0, (size_t)p->G * 8 * s.H * 4, st) != hipSuccess || hipMemsetAsync(p->qkv, 0, (size_t)8 * s.qkv() * 8, st) != hipSuccess) {
         fy_set_error("decode_create: memset failed");
@@ -988,9 +995,11 @@ int decode_step(DecodePlan* p, int B, float* h, const int* st_block, const float
     return FY_OK;
 }
 
-// true once a hand-off of some launch on this plan has timed out (read after a stream synchronisation)
+// != 0 once a hand-off of some launch on this plan has timed out since the last call (read after a stream synchronisation);
+// the word is cleared behind the copy, so one time-out is reported once and the handle stays usable on either decode path
 int decode_status(DecodePlan* p, unsigned* out, hipStream_t stream) {
     HIP_TRY(hipMemcpyAsync(out, p->status, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemsetAsync(p->status, 0, 4, stream));
     return FY_OK;
 }
 

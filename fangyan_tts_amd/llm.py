@@ -32,6 +32,7 @@ class LlmEngine:
         self._h = C.c_void_p()
         weights = {k: v for k, v in weights.items() if "lm_head" not in k}
         self._weights = weights if keep_weights else None          # needed only for load_state_dict
+        self._peers = []          # other handles built from the same weights (a model's extra LM handles and lanes): they follow load_state_dict
         self._create(weights)
 
     def _create(self, weights):
@@ -56,8 +57,9 @@ class LlmEngine:
                 if tuple(v.shape) != tuple(self._weights[k].shape):
                     raise RuntimeError(f"size mismatch for {k}: {tuple(v.shape)} vs {tuple(self._weights[k].shape)}")
                 self._weights[k] = v.detach().to(self.device, torch.float32).contiguous()
-        self.close()
-        self._create(self._weights)
+        for e in [self] + list(self._peers):                      # every handle that was built from these weights
+            e.close()
+            e._create(self._weights)
         return missing, unexpected
 
     def _stream(self):

@@ -80,6 +80,33 @@ def test_tiny_tokens_bit_exact_batched(tiny):
     run_cases(tiny, f, [(12, 8, 0), (10, 6, 30)], None, "tiny")
 
 
+@pytest.mark.parametrize("size,n_rows", [("tiny", 12), ("tiny", 40), ("full", 20), ("full", 37)])
+def test_many_rows_per_weight_pass(size, n_rows):
+    """More than 8 sequences decode together on the per-operation path (what tts_pipeline's LM call over several steps'
+    batches does): one weight pass serves 32 rows (gemv32.hip), 33+ rows take a second slice.  Every row must still emit the
+    ids of the reference fixture for its case - the rows are independent, whatever slot and slice they sit in."""
+    cfg = LlmCfg.tiny() if size == "tiny" else LlmCfg()
+    f = golden(f"llm_{size}.npz")
+    if f is None:
+        pytest.skip(f"llm_{size}.npz not minted")
+    base = [(12, 8, 0), (10, 6, 30)] if size == "tiny" else [(12, 8, 0), (14, 10, 40)]
+    cap = None if size == "tiny" else 40
+    eng = make(cfg, max_batch=n_rows, max_ctx=512 if size == "tiny" else 160)
+    try:
+        eng.set_decode_mode(False)
+        cases = [base[(b * 7 // 3) % 2] for b in range(n_rows)]          # an irregular mix over the slots
+        texts, ptexts, ptoks = (list(x) for x in zip(*[llm_case(cfg, *c, "%d_%d_%d" % c) for c in cases]))
+        max_len = [cap if cap else int(len(t) * 20) for t in texts]
+        out, out_n, _ = eng.generate(texts, ptexts, ptoks, max_len=max_len)
+        out, out_n = out.cpu(), out_n.cpu().tolist()
+        for b, c in enumerate(cases):
+            ref = f["c%d_%d_%d.tokens" % c].tolist()
+            ref = ref[:cap] if cap else ref
+            assert out[b, : out_n[b]].tolist() == ref, (b, c)
+    finally:
+        eng.close()
+
+
 def test_tiny_solo_equals_batched(tiny):
     f = golden("llm_tiny.npz")
     run_cases(tiny, f, [(10, 6, 30)], None, "tiny_solo")
