@@ -139,7 +139,41 @@ def spawn_ranks(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, steps=3):
+def _stage_profile(L, _lib, fn, names=("gemm_bf16", "conv_mfma", "gemv", "llm_decode", "gemm_exact")):
+    """One call of fn() with HIP events around every profiled launch: {name: (ms, work, launches)}."""
+    L.fy_prof_reset()
+    L.fy_prof_enable(1)
+    fn()
+    torch.cuda.synchronize()
+    L.fy_prof_enable(0)
+    out = {k: _lib.prof_get(k) for k in names}
+    L.fy_prof_reset()
+    return out
+
+
+def _pmc(name, *keys):
+    """A figure from this round's PMC summary under profiles/ (rocprofv3 --pmc, collected as the guide's HBM section prescribes);
+    None when the file or the key is absent."""
+    p = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(p):
+        return None
+    d = json.load(open(p))
+    for k in keys:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def dit_roofline(ms, flops, n, where, traffic):
+    ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    return {"bound": "mfma", "kernel": "DiT linears: gemm256_k (LDS-DMA ring; per shape 320x256 tiles with staggered wave groups, 256x128 or 128x128 tiles on 16x16x32 MFMAs)",
+            "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "HBM-side bytes per launch, mean over the DiT's products (rocprofv3 --pmc, profiles/r03_gemm_pmc.json)",
+            "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2), "gflop_per_launch": round(flops / max(n, 1) / 1e9, 3), "measured_over": where}
+
+
+def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib, steps=3):
     """BASELINE.json configs[2] as a secondary object: zero-shot with a 10 s prompt (30 prompt-text ids, 250 prompt speech
     tokens in the LM = a ~296-row prefill per sequence, 500 prompt mel frames: DiT sequence 650), batch 4, 75 forced tokens,
     steps one after the other on one stream."""
@@ -170,8 +204,28 @@ def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, steps=3):
         wav, samples, _ = m.tts_batch(inputs, min_len=forced, max_len=forced)          # wavs end on the host
     dt = (time.perf_counter() - t0) / steps
     audio = sum(samples) / 24000.0
+    # where the time goes: the LM alone (prefill of 4 x 296 rows + 75 token steps), then every profiled stage of one step
+    text = [d["text"].reshape(-1).tolist() for d in inputs]
+    ptext = [d["prompt_text"].reshape(-1).tolist() for d in inputs]
+    ptoks = [d["llm_prompt_speech_token"].reshape(-1).tolist() for d in inputs]
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    m.llm.generate(text, ptext, ptoks, min_len=forced, max_len=forced)
+    torch.cuda.synchronize()
+    lm_ms = 1e3 * (time.perf_counter() - t1)
+    prof = _stage_profile(L, _lib, lambda: m.tts_batch(inputs, min_len=forced, max_len=forced))
+    ms, flops, n = prof["gemm_bf16"]
+    ms_d, bytes_d, n_d = prof["llm_decode"]
     out = {"workload": "CosyVoice3-0.5B zero-shot, batch 4, 10 s prompt (250 LM prompt tokens, DiT sequence 650), 75 forced tokens each, unpipelined",
-           "ms": round(1e3 * dt, 2), "audio_s_per_s": round(audio / dt, 2), "steps": steps, "lm_decode": "persistent" if m.llm.persistent else "per-op"}
+           "ms": round(1e3 * dt, 2), "audio_s_per_s": round(audio / dt, 2), "steps": steps, "lm_decode": "persistent" if m.llm.persistent else "per-op",
+           "stage_split_ms": {"lm_generate_alone": round(lm_ms, 2), "flow_and_vocoder": round(1e3 * dt - lm_ms, 2),
+                              "by_events_in_one_step": {"dit_linears": round(ms, 2), "vocoder_convs": round(prof["conv_mfma"][0], 2),
+                                                        "lm_decode_launches": round(ms_d, 2), "lm_prefill_gemms": round(prof["gemm_exact"][0], 2),
+                                                        "lm_8_or_32_row_products": round(prof["gemv"][0], 2)}},
+           "roofline": dit_roofline(ms, flops, n, "HIP events on the launch stream around every DiT linear of one step (8 sequences x 650 rows: M = 5200)", None),
+           "roofline_lm": {"bound": "hbm", "kernel": "llm_decode_k (persistent token step, 4 sequences)", "achieved": round(bytes_d / (ms_d * 1e-3) / 1e9, 1) if ms_d else None,
+                           "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(bytes_d / (ms_d * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4) if ms_d else None,
+                           "launches": n_d, "avg_launch_us": round(1e3 * ms_d / max(n_d, 1), 1)}}
     del m
     torch.cuda.empty_cache()
     return out
@@ -210,15 +264,15 @@ def log(msg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (zero-shot batch 4, HiFT-only config 5)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary objects (zero-shot batch 4, HiFT-only config 5, ...)")
     ap.add_argument("--no-pipeline", action="store_true", help="run the steps strictly one after another")
-    ap.add_argument("--llm-streams", type=int, default=3, help="LM handles decoding different steps' batches concurrently")
+    ap.add_argument("--llm-streams", type=int, default=1, help="LM handles decoding different steps' batches concurrently")
     ap.add_argument("--lm-isolate", action="store_true", help="LM streams run ONLY on the CUs the flow stream is kept off")
-    ap.add_argument("--lm-group", type=int, default=1, help="consecutive steps whose LM decode runs as one call")
-    ap.add_argument("--flow-cu-exclude", type=int, default=None, help="CUs kept clear of the flow / vocoder stream")
+    ap.add_argument("--lm-group", type=int, default=4, help="consecutive steps whose LM decode runs as one call (32 rows per weight pass)")
+    ap.add_argument("--flow-cu-exclude", type=int, default=0, help="CUs kept clear of the flow / vocoder stream")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -261,9 +315,11 @@ def main():
     noise = torch.from_numpy(synth.flow_rand_noise(T)).to(dev)
     ri = torch.from_numpy(synth.hift_rand_ini()).to(dev)
     sn = torch.from_numpy(synth.hift_sine_noise(2 * N_TOK * 480)).to(dev)
+    pipelined = not a.no_pipeline
+    n_llm, group = (a.llm_streams, a.lm_group) if pipelined else (1, 1)
     model = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=BATCH, max_text=64, max_prompt_tokens=P_TOK,
-                            max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn, n_llm=1 if a.no_pipeline else a.llm_streams, lm_group=1 if a.no_pipeline else a.lm_group)
-    if not a.no_pipeline:
+                            max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn, n_llm=n_llm, lm_group=group)
+    if pipelined:
         model.prepare_pipeline(a.flow_cu_exclude)        # stream placement on the hardware pipes: set-up, not part of a step
     log("engines ready")
     inputs = make_inputs(cfg, rank)
@@ -284,9 +340,10 @@ def main():
         return deliver(*model.tts_batch(inputs, min_len=forced, max_len=forced, keep_on_device=True))
 
     def run(k):
-        """k steps.  Consecutive steps are software-pipelined over HIP streams (the LM of the next steps beside the
-        flow decoder + vocoder of step i); every step still runs the whole path on its own batch."""
-        if a.no_pipeline:
+        """k steps.  Consecutive steps are software-pipelined over HIP streams: the speech-token LM decodes the batches of
+        `lm_group` consecutive steps in ONE call (32 sequences per weight pass) beside the flow decoder + vocoder of the
+        steps before; every step still runs the whole path on its own batch of 8, inside the timed region."""
+        if not pipelined:
             return [step() for _ in range(k)][-1]
         samples = None
         for out in model.tts_pipeline([inputs] * k, min_len=[forced] * k, max_len=[forced] * k, keep_on_device=True,
@@ -309,18 +366,6 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     timed = {k: (v.clone() if torch.is_tensor(v) else [t.cpu() for t in v]) for k, v in last.items()}      # the last timed step's outputs
-    # roofline: the same K pipelined steps once more with HIP events around every launch of the dominant kernels (the DiT
-    # linears) on the stream they are launched on.  Not in the timed pass itself: the 1800 event records per step cost
-    # the flow stream ~6 % (88.5 against 83 ms per step); only that name is recorded, so the LM threads pay nothing.
-    L.fy_prof_reset()
-    L.fy_prof_only(b"gemm_bf16")
-    L.fy_prof_enable(1)
-    run(a.steps)
-    torch.cuda.synchronize()
-    L.fy_prof_enable(0)
-    L.fy_prof_only(None)
-    ms_t, flops_t, n_t = _lib.prof_get("gemm_bf16")
-    L.fy_prof_reset()
     if world > 1:
         t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -328,108 +373,116 @@ def main():
     audio_per_step = world * sum(samples) / 24000.0
     value = audio_per_step * a.steps / dt
     log(f"timed {a.steps} steps: {1e3 * dt / a.steps:.1f} ms/step, {value:.1f} audio_s/s")
-    # un-pipelined latency of one batch, for reference
+
+    # ---- roofline of the timed configuration: the SAME K steps twice more, with HIP events (on the stream each kernel is
+    # launched on) around every launch of one kernel family per pass - the DiT linears on the flow stream, then the LM's
+    # decode products on the LM stream.  Not inside the timed pass itself: two event records per launch cost the recorded
+    # stream a few per cent.  Event-to-event intervals of a kernel that shares the chip include the time its workgroups wait
+    # for CUs the other stream holds, exactly as rocprofv3's begin/end stamps do (profiles/r03_bench_kernel_stats.csv).
+    def events_pass(name):
+        L.fy_prof_reset()
+        L.fy_prof_only(name.encode())
+        L.fy_prof_enable(1)
+        run(a.steps)
+        torch.cuda.synchronize()
+        L.fy_prof_enable(0)
+        L.fy_prof_only(None)
+        r = _lib.prof_get(name)
+        L.fy_prof_reset()
+        return r
+    ms_t, flops_t, n_t = events_pass("gemm_bf16")
+    ms_vt, bytes_vt, n_vt = events_pass("gemv")
+
+    # ---- one batch alone (no pipelining): what tts_batch takes, LM on the persistent one-launch token step
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     step()
     torch.cuda.synchronize()
     latency_ms = 1e3 * (time.perf_counter() - t1)
-
-    # one more step alone with every profiled stage recorded (stage_ms_per_step below)
-    L.fy_prof_reset()
-    L.fy_prof_enable(1)
-    step()
-    torch.cuda.synchronize()
-    L.fy_prof_enable(0)
-    prof = {k: _lib.prof_get(k) for k in ("gemm_bf16", "conv_mfma", "gemv")}
-    L.fy_prof_reset()
-    # Two event-based figures for the DiT linears.  (1) A step alone: the interval between the two events of a launch is the
-    # kernel's own duration - it agrees with rocprofv3's average for the pipelined command (profiles/r01_bench_kernel_stats_
-    # final.csv: 48.6 us) - and is what `achieved` uses.  (2) The repeat of the timed pipelined steps: there the interval
-    # also contains the time the flow stream waits for CUs that the LM streams hold, so it is longer than the kernel ran.
+    prof = _stage_profile(L, _lib, step)
     ms, flops, n = prof["gemm_bf16"]
-    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    # HBM-side traffic per launch of the same kernel on the same shapes: PMC counters cannot be read from
-    # inside this process, so the figure is the one rocprofv3 measured (profiles/r02_gemm_pmc.json says how)
-    traffic, pmc = None, os.path.join(ROOT, "profiles", "r02_gemm_pmc.json")
-    if os.path.exists(pmc):
-        traffic = json.load(open(pmc)).get("dit_mix_traffic_bytes_per_launch")
-    roofline = {"bound": "mfma", "kernel": "DiT linears: gemm256_k (LDS-DMA ring; per shape 320x256 tiles with staggered wave groups, 256x128 or 128x128 tiles on 16x16x32 MFMAs)", "achieved": round(achieved, 2),
-                "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "traffic_unit": "bytes per launch (rocprofv3 PMC on the stand-alone driver, profiles/r02_gemm_pmc.json)",
-                "launches_per_step": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2),
-                "gflop_per_launch": round(flops / max(n, 1) / 1e9, 3),
-                "measured_over": "HIP events on the launch stream around every launch of one step run alone after the timed region",
-                "inside_pipelined_steps": {"stream_interval_us_per_launch": round(1e3 * ms_t / max(n_t, 1), 2),
-                                           "tflops_over_that_interval": round(flops_t / (ms_t * 1e-3) / 1e12, 2) if ms_t > 0 else None,
-                                           "note": "a repeat of the K timed steps; beside the three LM streams the kernels run ~20 % longer and the stream spends longer between launches (DESIGN.md section 10)"},
-                "stage_ms_per_step_alone": {k: round(v[0], 3) for k, v in prof.items()}}
 
-    # The kernels that hold the GPU longest are the LM's decode products (gemv_lds_k / gemv_direct_k: 97 of the 122 launches of
-    # a token step, ~60 % of all kernel time by rocprofv3): HBM-bound by SURVEY 8(d) - the bf16 weights are streamed once per
-    # token step for the 8 rows.  Kernel level: algorithmic bytes (the weights of each product) over the HIP-event duration of
-    # every launch of the step run alone; step level: 727.8 MB over the un-instrumented time of a token step.
-    ms_v, bytes_v, n_v = prof["gemv"]
+    where_t = (f"HIP events on the launch stream around every launch, over a repeat of the {a.steps} timed steps in the timed configuration "
+               f"(pipelined: {pipelined})")
+    roofline = dit_roofline(ms_t, flops_t, n_t, where_t, _pmc("r03_gemm_pmc.json", "dit_mix_traffic_bytes_per_launch"))
+    roofline["why_this_kernel"] = ("the kernel family with the largest share of GPU time in the timed region (profiles/r03_bench_kernel_stats.csv); "
+                                   "bound MFMA: 2 M N K flop per launch, SURVEY 8(d)")
+    roofline["one_step_alone"] = dit_roofline(ms, flops, n, "the same events over one un-pipelined step (nothing else on the GPU)", None)
+    roofline["stage_ms_per_step_alone"] = {k: round(v[0], 3) for k, v in prof.items()}
+
+    # ---- the LM's decode products (second by GPU time): HBM-bound by SURVEY 8(d) - every bf16 weight is streamed once per token
+    # step, now for 32 rows (4 steps' batches) per pass.  algorithmic bytes = the weights of each product.
     text = [d["text"].reshape(-1).tolist() for d in inputs]
     ptext = [d["prompt_text"].reshape(-1).tolist() for d in inputs]
+    G = group
+    eng = model.llms[0]
+    was = eng.persistent
+    eng.set_decode_mode(False)
+    eng.generate(text * G, ptext * G, [[] for _ in range(BATCH * G)], min_len=forced * G, max_len=forced * G)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
-    model.llms[0].generate(text, ptext, [[] for _ in inputs], min_len=forced, max_len=forced)
+    eng.generate(text * G, ptext * G, [[] for _ in range(BATCH * G)], min_len=forced * G, max_len=forced * G)
     torch.cuda.synchronize()
     lm_ms = 1e3 * (time.perf_counter() - t2)
-    gv_traffic, gv_pmc = None, os.path.join(ROOT, "profiles", "r01_gemv_pmc.json")
-    if os.path.exists(gv_pmc):
-        sh = json.load(open(gv_pmc))["shapes"]
-        per_layer = sum(sh[k]["fetched_bytes"] for k in ("qkv+norm", "o_proj", "gate/up+norm", "down (split-K 4)"))
-        gv_traffic = int((cfg.llm.layers * per_layer + sh["head+norm"]["fetched_bytes"]) / (4 * cfg.llm.layers + 1))
-    gbps = bytes_v / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0
+    pv = _stage_profile(L, _lib, lambda: eng.generate(text * G, ptext * G, [[] for _ in range(BATCH * G)], min_len=forced * G, max_len=forced * G), names=("gemv",))
+    ms_v, bytes_v, n_v = pv["gemv"]
+    eng.set_decode_mode(was)
     step_bytes = 727810048
-    roofline_lm = {"bound": "hbm", "kernel": "LM decode products: gemv_lds_k / gemv_direct_k (qkv, o-proj, gate/up, down of 24 layers + llm_decoder; 97 launches per token step)",
-                   "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
-                   "traffic": gv_traffic, "traffic_unit": "bytes per launch, mean over a token step (rocprofv3 PMC on the stand-alone driver, profiles/r01_gemv_pmc.json)",
-                   "launches_per_step": n_v, "avg_launch_us": round(1e3 * ms_v / max(n_v, 1), 2),
-                   "algorithmic_bytes_per_launch": int(bytes_v / max(n_v, 1)),
-                   "measured_over": "HIP events on the launch stream around every launch of one step run alone; the two event records add ~2 us to a ~10 us "
-                                    "launch (rocprofv3 over bench.py --no-pipeline: 10.1 us, profiles/r01_bench_nopipeline_kernel_stats.csv)",
-                   "decode_step_level": {"weight_bytes_per_token_step": step_bytes, "ms_per_token_step": round(lm_ms / N_TOK, 4),
-                                         "GBps": round(step_bytes / (lm_ms / N_TOK * 1e-3) / 1e9, 1),
-                                         "note": "un-instrumented LM call alone (prefill of ~25 rows per sequence included); bound by 122 dependent launches per token, not by bandwidth"}}
+    gb_t = bytes_vt / (ms_vt * 1e-3) / 1e9 if ms_vt > 0 else 0.0
+    gb_a = bytes_v / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0
+    roofline_lm = {"bound": "hbm", "kernel": f"LM decode products at {BATCH * G} rows per weight pass: gemv32_k (qkv, o-proj, gate/up, down of 24 layers + llm_decoder; 97 launches per token step)",
+                   "achieved": round(gb_t, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gb_t / PEAK_HBM_GBPS, 4),
+                   "traffic": _pmc("r03_gemv32_pmc.json", "traffic_bytes_per_launch"),
+                   "traffic_unit": "HBM-side bytes per launch, mean over a token step (rocprofv3 --pmc, profiles/r03_gemv32_pmc.json)",
+                   "launches": n_vt, "avg_launch_us": round(1e3 * ms_vt / max(n_vt, 1), 2), "algorithmic_bytes_per_launch": int(bytes_vt / max(n_vt, 1)),
+                   "measured_over": where_t,
+                   "one_generation_alone": {"achieved": round(gb_a, 1), "frac": round(gb_a / PEAK_HBM_GBPS, 4), "avg_launch_us": round(1e3 * ms_v / max(n_v, 1), 2), "launches": n_v,
+                                            "generate_ms": round(lm_ms, 2), "rows": BATCH * G, "ms_per_token_step": round(lm_ms / N_TOK, 4),
+                                            "weight_GBps_at_token_step_level": round(step_bytes / (lm_ms / N_TOK * 1e-3) / 1e9, 1),
+                                            "note": "one LM call alone (prefill included in generate_ms); a token step is 122 dependent launches: latency-bound, not bandwidth-bound"}}
 
-    # The same decode as ONE persistent launch per token step (llm_decode.hip; what a single LM stream uses - tts, tts_batch,
-    # stream=True; the pipelined steps above keep the per-operation launches because three LM streams interleave with the flow
-    # decoder, which a 152-CU persistent grid cannot): HIP events around every launch of a generation run alone.
+    # ---- the same decode as ONE persistent launch per token step (llm_decode.hip; what tts / tts_batch / stream=True use for up
+    # to 8 sequences): HIP events around every launch of a generation run alone.
     roofline_lm_p = None
-    if True:
-        eng = model.llms[0]
-        eng.set_decode_mode(True)
-        if eng.persistent:
-            eng.generate(text, ptext, [[] for _ in inputs], min_len=forced, max_len=forced)
+    eng.set_decode_mode(True)
+    if eng.persistent:
+        none8 = [[] for _ in inputs]
+        eng.generate(text, ptext, none8, min_len=forced, max_len=forced)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        eng.generate(text, ptext, none8, min_len=forced, max_len=forced)
+        torch.cuda.synchronize()
+        lm_p_ms = 1e3 * (time.perf_counter() - t3)
+        pp = _stage_profile(L, _lib, lambda: eng.generate(text, ptext, none8, min_len=forced, max_len=forced), names=("llm_decode",))
+        ms_p, bytes_p, n_p = pp["llm_decode"]
+        gb = bytes_p / (ms_p * 1e-3) / 1e9 if ms_p > 0 else 0.0
+        roofline_lm_p = {"bound": "hbm", "kernel": "llm_decode_k: one persistent launch per token step (24 layers + llm_decoder, 152 workgroups, "
+                         "weights register-resident a layer ahead, 121 grid-wide hand-offs)", "achieved": round(gb, 1), "peak": PEAK_HBM_GBPS,
+                         "unit": "GB/s", "frac": round(gb / PEAK_HBM_GBPS, 4),
+                         "traffic": _pmc("r03_llm_decode_pmc.json", "kernels", "llm_decode_k", "traffic_bytes") or _pmc("r02_llm_decode_pmc.json", "kernels", "llm_decode_k", "traffic_bytes"),
+                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc, profiles/r0x_llm_decode_pmc.json: kernels.llm_decode_k.traffic_bytes)",
+                         "launches": n_p, "avg_launch_us": round(1e3 * ms_p / max(n_p, 1), 1), "algorithmic_bytes_per_launch": int(bytes_p / max(n_p, 1)),
+                         "generate_ms_batch8_75_tokens": round(lm_p_ms, 2),
+                         "measured_over": "HIP events on the launch stream around every launch of one 75-token generation at batch 8, run alone"}
+    eng.set_decode_mode(was)
+
+    # ---- the price of the reference's own estimator-swap bar (rtol 1e-2 / atol 1e-4, export_onnx.py:109): the flow decoder in its
+    # fp32-class mode (FY_PRECISE: split operands, fp32 attention), un-pipelined steps
+    precise = None
+    if rank == 0 and world == 1 and not a.no_extras:
+        model.flow_flags = _lib.FY_PRECISE
+        try:
+            step()
             torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            eng.generate(text, ptext, [[] for _ in inputs], min_len=forced, max_len=forced)
+            t4 = time.perf_counter()
+            for _ in range(3):
+                step()
             torch.cuda.synchronize()
-            lm_p_ms = 1e3 * (time.perf_counter() - t3)
-            L.fy_prof_reset()
-            L.fy_prof_only(b"llm_decode")
-            L.fy_prof_enable(1)
-            eng.generate(text, ptext, [[] for _ in inputs], min_len=forced, max_len=forced)
-            torch.cuda.synchronize()
-            L.fy_prof_enable(0)
-            L.fy_prof_only(None)
-            ms_p, bytes_p, n_p = _lib.prof_get("llm_decode")
-            L.fy_prof_reset()
-            gb = bytes_p / (ms_p * 1e-3) / 1e9 if ms_p > 0 else 0.0
-            pmc_p, tr_p = os.path.join(ROOT, "profiles", "r02_llm_decode_pmc.json"), None
-            if os.path.exists(pmc_p):
-                tr_p = json.load(open(pmc_p)).get("traffic_bytes_per_launch")
-            roofline_lm_p = {"bound": "hbm", "kernel": "llm_decode_k: one persistent launch per token step (24 layers + llm_decoder, 152 workgroups, "
-                             "weights register-resident a layer ahead, 121 grid-wide hand-offs)", "achieved": round(gb, 1), "peak": PEAK_HBM_GBPS,
-                             "unit": "GB/s", "frac": round(gb / PEAK_HBM_GBPS, 4), "traffic": tr_p,
-                             "traffic_unit": "bytes per launch (rocprofv3 PMC over this process, profiles/r02_llm_decode_pmc.json)",
-                             "launches": n_p, "avg_launch_us": round(1e3 * ms_p / max(n_p, 1), 1), "algorithmic_bytes_per_launch": int(bytes_p / max(n_p, 1)),
-                             "generate_ms_batch8_75_tokens": round(lm_p_ms, 2),
-                             "measured_over": "HIP events on the launch stream around every launch of one 75-token generation at batch 8, run alone"}
-        eng.set_decode_mode(len(model.llms) == 1)
+            p_ms = 1e3 * (time.perf_counter() - t4) / 3
+        finally:
+            model.flow_flags = 0
+        precise = {"what": "one batch alone with the flow decoder in FY_PRECISE mode (meets rtol 1e-2 / atol 1e-4 against the fp32 estimator, tests/test_flow_gpu.py)",
+                   "ms": round(p_ms, 2), "audio_s_per_s": round(audio_per_step / (p_ms * 1e-3), 2), "default_mode_ms": round(latency_ms, 2)}
 
     out = {
         "metric": "synthesised audio sec/sec (RTF^-1) CosyVoice3-0.5B instruct, batch 8",
@@ -439,24 +492,33 @@ def main():
         "config": {"workload": "CosyVoice3-0.5B instruct (inference_instruct2), batch 8 mixed-length utterances per GPU, "
                                "5 s prompt, 75 forced speech tokens (3 s) each, LM greedy -> 10-step CFG flow (DiT-22) -> HiFT",
                    "batch_per_gpu": BATCH, "tokens_per_utt": N_TOK, "prompt_tokens": P_TOK, "parallelism": f"dp{world}",
-                   "steps_pipelined": not a.no_pipeline, "llm_streams": 1 if a.no_pipeline else a.llm_streams, "lm_group": 1 if a.no_pipeline else a.lm_group, "flow_cu_exclude": a.flow_cu_exclude, "batch_latency_ms_unpipelined": round(latency_ms, 1),
+                   "steps_pipelined": pipelined, "llm_streams": n_llm, "lm_group": group,
+                   "lm_rows_per_weight_pass": BATCH * group,
+                   "utterances_in_flight_max": BATCH * (3 * group * n_llm + 1) if pipelined else BATCH,
+                   "in_flight_note": "one LM call decodes lm_group steps' batches together; the ids of up to 2 x lm_group finished batches wait in a queue; one batch is in the flow decoder / vocoder",
+                   "flow_cu_exclude": a.flow_cu_exclude, "batch_latency_ms_unpipelined": round(latency_ms, 1),
                    "weights": "random-init, CosyVoice3-0.5B shapes (859 M params)"},
-        "roofline": roofline_lm,
+        # the strict batch-8 figure: one batch at a time, nothing of another batch in flight (tts_batch; LM on the persistent step)
+        "value_batch8_unpipelined": round(audio_per_step / (latency_ms * 1e-3), 2),
+        "roofline": roofline,
+        "roofline_lm": roofline_lm,
         "roofline_lm_persistent": roofline_lm_p,
-        "roofline_dit_linears": roofline,
+        "precise_mode": precise,
     }
     if rank == 0 and world == 1 and not a.no_extras:
         # behind the timed region: BASELINE.json configs[0], configs[2] and configs[4] as secondary objects of the same record
         log("one utterance alone (config 1's shape)")
         out["latency_b1"] = bench_latency_b1(cfg, sd_llm, sd_flow, sd_hift, dev, inputs)
         log("zero-shot batch 4 (config 3)")
-        out["zero_shot_b4"] = bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev)
+        out["zero_shot_b4"] = bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib)
         log("HiFT-only 32 x 10 000 frames (config 5)")
-        del model
+        model.close()
+        del model, eng
         torch.cuda.empty_cache()
         import bench_hift
         h5 = bench_hift.run(steps=2, warmup=1)
-        out["hift_cfg5"] = {"workload": h5["config"]["workload"], "ms": h5["ms_per_step"], "audio_s_per_s": h5["value"], "roofline": h5["roofline"]}
+        out["hift_cfg5"] = {"workload": h5["config"]["workload"], "ms": h5["ms_per_step"], "audio_s_per_s": h5["value"], "roofline": h5["roofline"],
+                            "checked": h5["checked"]}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("timing the CPU oracle on one utterance")
         out["cpu_baseline"], out["checked"] = cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inputs[0], noise, ri, sn, timed)

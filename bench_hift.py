@@ -28,11 +28,38 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--no-check", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(run(a.batch, a.frames, a.steps, a.warmup, a.flags)))
+    print(json.dumps(run(a.batch, a.frames, a.steps, a.warmup, a.flags, check=not a.no_check)))
 
 
-def run(batch=32, frames=10000, steps=3, warmup=1, flags=0):
+def check_output(eng, cfg, sd, mel, ri, sn, wav, flags, prefix_frames=1000):
+    """What the timed call produced, checked without a reference of that size (size-independent properties) plus the
+    CPU oracle where it is affordable:
+      * the LAST utterance of the batch (its stage tensors sit beyond 2^31 elements at 32 x 10 000 frames) equals a solo run
+        of its own mel (batch = solo, <= 1e-5: the kernels are batch-invariant up to the last bit or two);
+      * utterance 0's first `prefix_frames` frames against the oracle vocoder (oracle/hift.py, CPU fp32) on the mel prefix plus
+        the 4 frames conv_pre looks ahead (the net is causal: CosyVoice/cosyvoice/hifigan/generator.py:739-746), tolerance 2.5e-3
+        as in tests/test_e2e_gpu.py (bf16 MFMA operands; measured 5-9e-4);
+      * |wav| <= 0.99 (the clamp of generator.py:746) and no NaN."""
+    from oracle import hift as ohift
+    B, _, F = mel.shape
+    up = cfg.upsample_total
+    solo, _ = eng.inference(mel[B - 1: B].contiguous(), ri, sn, flags=flags)
+    e_solo = float((wav[B - 1: B] - solo).abs().max())
+    del solo
+    n = min(prefix_frames, F - 4)
+    P = ohift.prepare({k: v.cpu().numpy() for k, v in sd.items()})
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
+    ref, _ = ohift.inference(mel[0:1, :, : n + 4].cpu(), P, cfg, ri.cpu(), sn[:, : (n + 4) * up].cpu())
+    e_ref = float((wav[0:1, : n * up].cpu() - ref[:, : n * up]).abs().max())
+    peak, finite = float(wav.abs().max()), bool(torch.isfinite(wav).all())
+    return {"what": f"last utterance of the batch vs a solo run of its mel; utterance 0's first {n} frames vs the CPU oracle vocoder; clamp; finite",
+            "last_utterance_vs_solo_max_abs": round(e_solo, 8), "solo_tol": 1e-5, "utt0_prefix_vs_oracle_max_abs": round(e_ref, 6), "oracle_tol": 2.5e-3,
+            "peak_abs": round(peak, 4), "finite": finite, "ok": bool(e_solo <= 1e-5 and e_ref <= 2.5e-3 and peak <= 0.99 + 1e-6 and finite)}
+
+
+def run(batch=32, frames=10000, steps=3, warmup=1, flags=0, check=True):
     """BASELINE.json configs[4] as a function (bench.py reports it as "hift_cfg5")."""
     import types
     a = types.SimpleNamespace(batch=batch, frames=frames, steps=steps, warmup=warmup, flags=flags)
@@ -62,13 +89,17 @@ def run(batch=32, frames=10000, steps=3, warmup=1, flags=0):
     L.fy_prof_enable(0)
     ms, flops, n = _lib.prof_get("conv_mfma")
     L.fy_prof_reset()
+    checked = check_output(eng, cfg, sd, mel, ri, sn, wav, a.flags) if check else None
     frames = a.batch * a.frames
     audio = frames * 480 / 24000.0
     # HBM-side traffic: rocprofv3 --pmc cannot sit under a torch process on this pool, so the per-frame figure is the one
     # measured on the stand-alone driver of the same engine (profiles/r02_hift_pmc.json says how), scaled to this run
-    traffic, pmc = None, os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_hift_pmc.json")
-    if os.path.exists(pmc) and a.flags == 0:
-        traffic = int(json.load(open(pmc))["traffic_bytes_per_frame"] * frames)
+    traffic, pmc_name = None, None
+    for pmc_name in ("r03_hift_pmc.json", "r02_hift_pmc.json"):
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
+        if os.path.exists(pmc) and a.flags == 0:
+            traffic = int(json.load(open(pmc))["traffic_bytes_per_frame"] * frames)
+            break
     bw = frames * BYTES_PER_FRAME / dt
     del eng, mel, sn, wav
     torch.cuda.empty_cache()
@@ -76,11 +107,12 @@ def run(batch=32, frames=10000, steps=3, warmup=1, flags=0):
         "metric": "HiFT vocoder audio sec/sec", "value": round(audio / dt, 1), "unit": "audio_s/s", "ms_per_step": round(1e3 * dt, 2),
         "config": {"workload": f"HiFT-only, random mel, batch {a.batch} x {a.frames} frames", "flags": a.flags},
         "roofline": {"bound": "hbm", "achieved": round(bw / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(bw / HBM_PEAK, 4),
-                     "traffic": traffic, "traffic_unit": "bytes per step (L2-miss bytes per frame from profiles/r02_hift_pmc.json x frames)",
+                     "traffic": traffic, "traffic_unit": f"bytes per step (L2-miss bytes per frame from profiles/{pmc_name} x frames)",
                      "frac_on_counter_bytes": round(traffic / dt / HBM_PEAK, 4) if traffic else None,
                      "algorithmic_bytes": int(frames * BYTES_PER_FRAME), "algorithmic_tflops": round(frames * FLOP_PER_FRAME / dt / 1e12, 1),
                      "conv_mfma_ms": round(ms, 2), "conv_mfma_tflops": round(flops / (ms * 1e-3) / 1e12, 1) if ms else None,
-                     "conv_mfma_launches": n}})
+                     "conv_mfma_launches": n},
+        "checked": checked})
 
 
 if __name__ == "__main__":

@@ -100,7 +100,7 @@ static std::mutex g_prof_mu;
 ProfScope::ProfScope(const char* name, double work, hipStream_t s) : st(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (!g_prof_only.empty() && g_prof_only != name) return;
+    if (!g_prof_only.empty() && ("," + g_prof_only + ",").find(std::string(",") + name + ",") == std::string::npos) return;      // a comma-separated list
     ProfRec r;
     r.name = name; r.work = work;
     if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;

@@ -115,3 +115,83 @@ def test_hift_long_mel_causal_prefix_property():
     note("parity_configs.json", "hift.long_prefix.max", e)
     assert e < 1e-5
     assert float(full.abs().max()) <= 0.99 + 1e-6
+
+
+def test_hift_config5_full_size_properties():
+    """BASELINE.json configs[4] at its FULL size - 32 utterances x 10 000 frames, the shape bench_hift.py times - checked
+    through properties that do not need a reference of that size (the stage tensors pass 2^31 elements here, which is
+    where an index width shows):
+      * ragged batch = solo: utterances 0 and 31 (the last one, 9 000 frames in a ragged batch) equal solo runs of their own mel;
+      * causal prefix: utterance 31's first 5 000 frames equal a solo run of its first 5 004 frames (conv_pre looks 4 ahead).
+        The prefix is longer than 4 096 frames on purpose: the exact-fp32 f0 predictor picks its launch form (K split over
+        the waves or not) from the sequence length, so a SHORT prefix sums in another order, f0 moves in the last bit and the
+        harmonic source integrates that over a thousand frames (measured 7.6e-4 on the waveform for a 1 004-frame prefix -
+        an fp32 ordering effect, checked at the vocoder's stated tolerance below, not a causality leak);
+      * |wav| <= 0.99 (generator.py:746 clamp), no NaN, and the ragged tail beyond an utterance's length is silent."""
+    from fangyan_tts_amd.hift import HiftEngine
+    cfg = HiftCfg()
+    sd = synth.state_dict_torch(cfg.manifest(), DEV)
+    B, F = 32, 10000
+    eng = HiftEngine(sd, cfg, max_batch=B, max_frames=F)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    mel = torch.rand(B, 80, F, device=DEV, generator=g)
+    ri = torch.from_numpy(synth.hift_rand_ini()).to(DEV)
+    sn = torch.rand(1, F * 480, 9, device=DEV, generator=g)
+    frames = [F] * B
+    frames[31], frames[7] = 9000, 6001
+    wav, _ = eng.inference(mel, ri, sn, frames=frames)
+    assert wav.shape == (B, F * 480)
+    assert bool(torch.isfinite(wav).all()) and float(wav.abs().max()) <= 0.99 + 1e-6
+    assert float(wav[31, 9000 * 480:].abs().max()) == 0.0 and float(wav[7, 6001 * 480:].abs().max()) == 0.0
+    for b in (0, 31):
+        solo, _ = eng.inference(mel[b: b + 1, :, : frames[b]].contiguous(), ri, sn)
+        e = maxerr(wav[b: b + 1, : frames[b] * 480], solo[:, : frames[b] * 480])
+        note("parity_configs.json", f"hift.cfg5.ragged_equals_solo.{b}", e)
+        assert e < 1e-5, (b, e)
+    pre, _ = eng.inference(mel[31:32, :, :5004].contiguous(), ri, sn)
+    e = maxerr(wav[31:32, : 5000 * 480], pre[:, : 5000 * 480])
+    note("parity_configs.json", "hift.cfg5.prefix5000.31", e)
+    assert e < 1e-5
+    pre, _ = eng.inference(mel[31:32, :, :1004].contiguous(), ri, sn)
+    e = maxerr(wav[31:32, : 1000 * 480], pre[:, : 1000 * 480])
+    note("parity_configs.json", "hift.cfg5.prefix1000.31", e)
+    assert e < 2.5e-3                                  # the other launch form of the f0 convs: fp32 summation order (docstring)
+    eng.close()
+
+
+def test_instruct_batch8_full_size_against_oracle():
+    """BASELINE.json configs[1] at full size (CosyVoice3-0.5B shapes, 8 instruct utterances of mixed text length behind a 5 s
+    prompt, 75 forced tokens = the benchmark's batch): utterances 0 and 7 of the batch are held to the CPU oracle's whole
+    per-utterance path - ids exact, mel <= 4e-2 (bf16 flow decoder, measured ~1.3e-2), waveform <= 2.5e-3 from the oracle
+    vocoder run on the engine's own mel."""
+    import bench
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    from oracle import hift as ohift, pipeline as opipe
+    cfg = ModelCfg()
+    sd_llm = synth.state_dict_torch(cfg.llm.manifest(), DEV, skip=("lm_head",))
+    sd_flow = synth.state_dict_torch(cfg.flow.manifest(), DEV)
+    sd_hift = synth.state_dict_torch(cfg.hift.manifest(), DEV)
+    N, P = bench.N_TOK, bench.P_TOK
+    noise = torch.from_numpy(synth.flow_rand_noise(2 * (P + N))).to(DEV)
+    ri = torch.from_numpy(synth.hift_rand_ini()).to(DEV)
+    sn = torch.from_numpy(synth.hift_sine_noise(2 * N * 480)).to(DEV)
+    m = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=DEV, max_batch=8, max_text=64, max_prompt_tokens=P, max_tokens=N,
+                        rand_noise=noise, rand_ini=ri, sine_noise=sn)
+    inputs = bench.make_inputs(cfg, 0)
+    forced = [N] * 8
+    wav, samples, toks = m.tts_batch(inputs, min_len=forced, max_len=forced)
+    mel = m.last_mel.cpu()
+    torch.set_num_threads(16)
+    PL = {k: v.cpu() for k, v in sd_llm.items()}
+    PF = {k: v.cpu() for k, v in sd_flow.items()}
+    PH = ohift.prepare({k: v.cpu().numpy() for k, v in sd_hift.items()})
+    for b in (0, 7):
+        ref = opipe.tts(inputs[b], PL, PF, PH, cfg, noise.cpu(), ri.cpu(), sn.cpu(), min_len=N, max_len=N)
+        assert toks[b].cpu().reshape(-1).tolist() == ref["tokens"].reshape(-1).tolist(), b
+        e_mel = maxerr(mel[b: b + 1, :, : 2 * N], ref["mel"])
+        S = samples[b]
+        ref_wav, _ = ohift.inference(mel[b: b + 1, :, : 2 * N], PH, cfg.hift, ri.cpu(), sn.cpu()[:, :S])
+        e_wav = maxerr(wav[b: b + 1, :S], ref_wav)
+        note("parity_configs.json", f"instruct_b8_full.{b}", [e_mel, e_wav])
+        assert e_mel <= 4e-2 and e_wav <= 2.5e-3, (b, e_mel, e_wav)
+    m.close()

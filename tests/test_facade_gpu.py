@@ -208,3 +208,63 @@ def test_automodel_errors(tmp_path):
         AutoModel(model_dir=str(tmp_path / "nope"))
     with pytest.raises(TypeError):
         AutoModel(model_dir=str(tmp_path))
+
+
+def test_load_state_dict_reaches_every_lane(model_dir):
+    """compare_inference.py:42 swaps a fine-tuned LM in through `model.model.llm.load_state_dict`.  With concurrency=2 (two engine
+    sets) BOTH lanes must decode with the new weights: two threads inside tts() at once get the audio a one-lane model gets
+    after the same swap."""
+    import threading
+    from cosyvoice.cli.cosyvoice import AutoModel
+    path, cfg = model_dir
+    fe = FakeFrontEnd(cfg)
+    job = ("你好世界", "用四川话说<|endofprompt|>", "prompt.wav")
+    sd = {k: torch.from_numpy(v) * 0.5 for k, v in synth.state_dict(cfg.llm.manifest()).items() if "layers.1." in k}
+    ref_model = AutoModel(model_dir=path, frontend=fe, max_tokens=160, max_prompt_tokens=32, sampler="greedy")
+    before = list(ref_model.inference_instruct2(*job))[0]["tts_speech"]
+    ref_model.model.llm.load_state_dict(sd, strict=False)
+    after = list(ref_model.inference_instruct2(*job))[0]["tts_speech"]
+    assert after.shape != before.shape or maxerr(after, before) > 1e-4
+    model = AutoModel(model_dir=path, frontend=fe, max_tokens=160, max_prompt_tokens=32, sampler="greedy", concurrency=2)
+    model.model.llm.load_state_dict(sd, strict=False)
+    got, errs = [None, None], []
+    gate = threading.Barrier(2)
+
+    def work(i):
+        try:
+            gate.wait()                            # both inside tts() together: one call per lane
+            got[i] = list(model.inference_instruct2(*job))[0]["tts_speech"]
+        except BaseException as e:                # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert got[i].shape == after.shape and maxerr(got[i], after) == 0.0, i
+    # and each lane on its own, whichever the queue hands out: every LM handle of the model was rebuilt
+    for ln in model.model.lanes:
+        out, out_n, _ = ln.llm.generate([[5, 6, 7, 8]], [[1, 2]], [[]], max_len=[12])
+        ref, ref_n, _ = ref_model.model.llm.generate([[5, 6, 7, 8]], [[1, 2]], [[]], max_len=[12])
+        assert torch.equal(out.cpu(), ref.cpu()) and torch.equal(out_n.cpu(), ref_n.cpu())
+
+
+def test_abandoned_stream_generator_says_so(model_dir):
+    """A stream=True generator that is neither exhausted nor closed keeps the model's only lane; the next call on the same thread
+    must say so instead of waiting forever, and closing the generator frees the lane."""
+    from cosyvoice.cli.cosyvoice import AutoModel
+    path, cfg = model_dir
+    fe = FakeFrontEnd(cfg)
+    model = AutoModel(model_dir=path, frontend=fe, max_tokens=160, max_prompt_tokens=32, sampler="greedy")
+    job = ("你好世界今天天气不错", "用四川话说<|endofprompt|>", "prompt.wav")
+    whole = list(model.inference_instruct2(*job))[0]["tts_speech"]
+    gen = model.inference_instruct2(*job, stream=True)
+    first = next(gen)["tts_speech"]
+    assert first.shape[1] > 0
+    with pytest.raises(RuntimeError, match="every lane of this model is held by this thread"):
+        list(model.inference_instruct2(*job))
+    gen.close()
+    again = list(model.inference_instruct2(*job))[0]["tts_speech"]
+    assert again.shape == whole.shape and maxerr(again, whole) == 0.0
