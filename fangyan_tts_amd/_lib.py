@@ -109,6 +109,12 @@ def _declare(L):
     L.fy_prompt_mel_destroy.restype = None
     L.fy_prompt_mel_frames.argtypes = [i32]
     L.fy_prompt_mel_run.argtypes = [vp, vp, i32, vp, i32, vp]
+    L.fy_audio_feat_create.argtypes = [C.POINTER(vp), i32, vp]
+    L.fy_audio_feat_destroy.argtypes = [vp]
+    L.fy_audio_feat_destroy.restype = None
+    L.fy_audio_feat_mels.argtypes = [vp]
+    L.fy_audio_feat_frames.argtypes = [vp, C.c_int64]
+    L.fy_audio_feat_run.argtypes = [vp, vp, C.c_int64, vp, i32, u32, vp]
     L.fy_stream_create_masked.argtypes = [C.POINTER(vp), C.POINTER(C.c_uint32), i32]
     L.fy_stream_destroy.argtypes = [vp]
     L.fy_llm_set_decode_mode.argtypes = [vp, i32]

@@ -128,7 +128,11 @@ class CosyVoice3:
         dev = device or torch.device("cuda", torch.cuda.current_device())
         if frontend is None:
             # cli/cosyvoice.py:204-209: CosyVoiceFrontEnd(get_tokenizer, feat_extractor, campplus.onnx, speech_tokenizer_v3.onnx, spk2info.pt)
-            from .frontend import CosyVoiceFrontEnd, load_qwen_tokenizer
+            from .frontend import CosyVoiceFrontEnd, load_qwen_tokenizer, onnx_prompt_models
+            if speech_tokenizer is None and spk_embedder is None and dev.type == "cuda":
+                # the reference's own two ONNX sessions when onnxruntime imports and the files are there (cli/frontend.py:41-46);
+                # injected callables take precedence
+                speech_tokenizer, spk_embedder = onnx_prompt_models(model_dir, dev)
             try:
                 frontend = CosyVoiceFrontEnd(tokenizer if tokenizer is not None else load_qwen_tokenizer(model_dir),
                                              speech_tokenizer=speech_tokenizer, spk_embedder=spk_embedder,

@@ -160,10 +160,46 @@ def load_qwen_tokenizer(model_dir: str) -> QwenTokenizer:
 
 
 # ---- audio -------------------------------------------------------------------------------------------------------------
+def sinc_resample_kernel(orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99):
+    """The filter bank of torchaudio.transforms.Resample with its defaults (resampling_method "sinc_interp_hann",
+    lowpass_filter_width 6, rolloff 0.99; torchaudio/functional/functional.py:_get_sinc_resample_kernel, torchaudio 2.x), restated
+    from the published algorithm - torchaudio is not in the image, so this table is unpinned:
+    with o = orig / gcd, n = new / gcd, f = rolloff * min(o, n), width = ceil(lpw * o / f), phase j in [0, n) and tap
+    i in [-width, width + o):   t = clamp((-j / n + i / o) * f, -lpw, lpw);
+    kernel[j][i] = sinc(pi t) * cos(pi t / (2 lpw))^2 * f / o     (float64, stored as float32).  Returns (kernels (n, taps), width, o, n)."""
+    from math import ceil, gcd, pi
+    g = gcd(int(orig_freq), int(new_freq))
+    o, n = int(orig_freq) // g, int(new_freq) // g
+    base = min(o, n) * rolloff
+    width = int(ceil(lowpass_filter_width * o / base))
+    idx = torch.arange(-width, width + o, dtype=torch.float64)[None, :] / o
+    # torchaudio divides an int64 arange by new_freq: a float32 quotient, promoted to float64 when idx is added
+    t = (torch.arange(0, -n, -1, dtype=torch.int64)[:, None] / n).to(torch.float64) + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * pi / lowpass_filter_width / 2) ** 2
+    t = t * pi
+    k = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / o)
+    return k.to(torch.float32), width, o, n
+
+
+def resample(x: torch.Tensor, orig_freq: int, new_freq: int) -> torch.Tensor:
+    """torchaudio.transforms.Resample(orig_freq, new_freq)(x) for x (channels, S) (functional.py:_apply_sinc_resample_kernel):
+    pad (width, width + o), correlate with the n phase filters at stride o, interleave the phases, keep ceil(n S / o) samples."""
+    if int(orig_freq) == int(new_freq):
+        return x
+    k, width, o, n = sinc_resample_kernel(orig_freq, new_freq)
+    S = x.shape[-1]
+    xp = torch.nn.functional.pad(x.to(torch.float32).reshape(-1, S), (width, width + o))
+    y = torch.nn.functional.conv1d(xp[:, None], k[:, None], stride=o)            # (channels, n, frames)
+    y = y.transpose(1, 2).reshape(xp.shape[0], -1)
+    target = -(-n * S // o)                                                         # ceil(n S / o)
+    return y[:, :target].reshape(x.shape[:-1] + (target,))
+
+
 def load_wav(wav, target_sr: int, min_sr: int = 16000) -> torch.Tensor:
     """utils/file_utils.py:44-50: mono (channel mean), resampled to target_sr -> float32 (1, S) in [-1, 1].
-    `wav`: a path to a PCM / float .wav, or (samples, sample_rate) with samples (S,) or (channels, S).  Resampling is
-    scipy.signal.resample_poly, NOT torchaudio's windowed-sinc kernel (torchaudio is absent): parity unpinned for it."""
+    `wav`: a path to a PCM / float .wav, or (samples, sample_rate) with samples (S,) or (channels, S).  Resampling restates
+    torchaudio.transforms.Resample's default windowed-sinc filter bank (`resample` above)."""
     if isinstance(wav, (tuple, list)):
         data, sr = wav
         x = torch.as_tensor(np.asarray(data), dtype=torch.float32)
@@ -181,10 +217,7 @@ def load_wav(wav, target_sr: int, min_sr: int = 16000) -> torch.Tensor:
     x = x.mean(dim=0, keepdim=True)
     if int(sr) != int(target_sr):
         assert sr >= min_sr, "wav sample rate {} must be greater than {}".format(sr, target_sr)
-        from math import gcd
-        from scipy.signal import resample_poly
-        g = gcd(int(sr), int(target_sr))
-        x = torch.from_numpy(resample_poly(x.numpy(), int(target_sr) // g, int(sr) // g, axis=1).astype(np.float32))
+        x = resample(x, int(sr), int(target_sr))
     return x
 
 
@@ -220,6 +253,78 @@ class PromptMel:
             pass
 
 
+class AudioFeat:
+    """The 16 kHz features of the reference's two ONNX models on the GPU (csrc/frontend_feats.hip):
+    kind "whisper": whisper.log_mel_spectrogram(speech, n_mels=128) -> (1, 128, frames)   (cli/frontend.py:97)
+    kind "fbank":   kaldi.fbank(speech, num_mel_bins=80, dither=0, sample_frequency=16000), minus its mean over the frames when
+                    subtract_mean -> (frames, 80)                                           (cli/frontend.py:111-115)"""
+
+    def __init__(self, kind: str, device: Optional[torch.device] = None):
+        from .. import _lib
+        assert kind in ("whisper", "fbank")
+        self._lib, self.kind = _lib, kind
+        self.device = device or torch.device("cuda", torch.cuda.current_device())
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().fy_audio_feat_create(C.byref(self._h), 0 if kind == "whisper" else 1, self._stream()))
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def __call__(self, speech: torch.Tensor, subtract_mean: bool = False) -> torch.Tensor:
+        x = speech.reshape(-1).to(self.device, torch.float32).contiguous()
+        L = self._lib.lib()
+        frames, mels = L.fy_audio_feat_frames(self._h, int(x.numel())), L.fy_audio_feat_mels(self._h)
+        if frames < 1:
+            raise ValueError(f"{x.numel()} samples are too few for one {self.kind} frame")
+        out = torch.empty((mels, frames) if self.kind == "whisper" else (frames, mels), device=self.device)
+        self._lib.check(L.fy_audio_feat_run(self._h, x.data_ptr(), int(x.numel()), out.data_ptr(), frames, 1 if subtract_mean else 0, self._stream()))
+        return out.unsqueeze(0) if self.kind == "whisper" else out
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.lib().fy_audio_feat_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+def onnx_prompt_models(model_dir: str, device: Optional[torch.device] = None):
+    """The reference's two ONNX sessions (cli/frontend.py:41-46: campplus.onnx on the CPU provider, speech_tokenizer_v3.onnx on the
+    GPU provider when there is one) over this package's feature kernels, as the callables CosyVoiceFrontEnd takes:
+    (speech_tokenizer(speech16k) -> list[int], spk_embedder(speech16k) -> (1, 192)).  (None, None) when onnxruntime does not
+    import or the files are missing - the caller then injects its own callables."""
+    try:
+        import onnxruntime
+    except Exception:
+        return None, None
+    camp, tok = os.path.join(model_dir, "campplus.onnx"), os.path.join(model_dir, "speech_tokenizer_v3.onnx")
+    if not (os.path.exists(camp) and os.path.exists(tok)):
+        return None, None
+    option = onnxruntime.SessionOptions()
+    option.graph_optimization_level = onnxruntime.GraphOptimizationLevel.ORT_ENABLE_ALL
+    option.intra_op_num_threads = 1
+    have = set(onnxruntime.get_available_providers())
+    gpu = [p for p in ("ROCMExecutionProvider", "MIGraphXExecutionProvider", "CUDAExecutionProvider") if p in have]
+    camp_s = onnxruntime.InferenceSession(camp, sess_options=option, providers=["CPUExecutionProvider"])
+    tok_s = onnxruntime.InferenceSession(tok, sess_options=option, providers=(gpu[:1] or []) + ["CPUExecutionProvider"])
+    whisper_feat, fbank = AudioFeat("whisper", device), AudioFeat("fbank", device)
+
+    def speech_tokenizer(speech16k):
+        assert speech16k.shape[1] / 16000 <= 30, "do not support extract speech token for audio longer than 30s"      # frontend.py:96
+        feat = whisper_feat(speech16k)
+        ins = tok_s.get_inputs()
+        return tok_s.run(None, {ins[0].name: feat.detach().cpu().numpy(),
+                                ins[1].name: np.array([feat.shape[2]], dtype=np.int32)})[0].flatten().tolist()
+
+    def spk_embedder(speech16k):
+        feat = fbank(speech16k, subtract_mean=True)
+        emb = camp_s.run(None, {camp_s.get_inputs()[0].name: feat.unsqueeze(dim=0).cpu().numpy()})[0].flatten().tolist()
+        return torch.tensor([emb])
+    return speech_tokenizer, spk_embedder
+
+
 def _missing(what: str, ref: str):
     def f(*a, **kw):
         raise NotImplementedError(f"{what} is not available here ({ref}); pass it to CosyVoiceFrontEnd(...) as a callable")
@@ -239,9 +344,11 @@ class CosyVoiceFrontEnd:
         self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.feat_extractor = feat_extractor if feat_extractor is not None else PromptMel(24000, self.device if self.device.type == "cuda" else None)
         self.speech_tokenizer = speech_tokenizer or _missing("the speech tokenizer (speech_tokenizer_v3.onnx over whisper's 128-bin log-mel)",
-                                                             "cli/frontend.py:94-108; onnxruntime and whisper are not installed")
+                                                             "cli/frontend.py:94-108; onnxruntime is not installed or the .onnx file is missing: "
+                                                             "AudioFeat('whisper') computes the model's input")
         self.spk_embedder = spk_embedder or _missing("the speaker embedder (campplus.onnx over an 80-bin kaldi fbank)",
-                                                     "cli/frontend.py:110-117; onnxruntime and torchaudio are not installed")
+                                                     "cli/frontend.py:110-117; onnxruntime is not installed or the .onnx file is missing: "
+                                                     "AudioFeat('fbank') computes the model's input")
         self.spk2info = torch.load(spk2info, map_location=self.device, weights_only=True) if spk2info and os.path.exists(spk2info) else {}
         self.allowed_special = allowed_special
         self.number_speller = number_speller                  # inflect.engine().number_to_words in the reference

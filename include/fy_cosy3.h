@@ -216,6 +216,21 @@ void fy_prompt_mel_destroy(fy_prompt_mel* p);
 int fy_prompt_mel_frames(int32_t n_samples);
 int fy_prompt_mel_run(fy_prompt_mel* p, const float* wav, int32_t n_samples, float* mel, int32_t frames, void* stream);
 
+/* ================================ frontend: the 16 kHz features of the two ONNX models ================================
+ * kind 0 replaces whisper.log_mel_spectrogram(speech, n_mels=128) of CosyVoiceFrontEnd._extract_speech_token
+ *        (cli/frontend.py:94-108; the input of speech_tokenizer_v3.onnx): out (128, frames), frames = n_samples / 160.
+ * kind 1 replaces torchaudio.compliance.kaldi.fbank(speech, num_mel_bins=80, dither=0, sample_frequency=16000) of
+ *        _extract_spk_embedding (cli/frontend.py:110-117; the input of campplus.onnx): out (frames, 80),
+ *        frames = 1 + (n_samples - 400) / 160; flags bit 0 also subtracts the mean over the frames (frontend.py:115).
+ * wav: device fp32 (n_samples) at 16 kHz in [-1, 1].  whisper and torchaudio are not in the image: both algorithms are
+ * restated from their published definitions (parity unpinned; the transforms are held to torch.stft / torch.fft by the tests). */
+typedef struct fy_audio_feat fy_audio_feat;
+int fy_audio_feat_create(fy_audio_feat** out, int32_t kind, void* stream);
+void fy_audio_feat_destroy(fy_audio_feat* p);
+int fy_audio_feat_mels(const fy_audio_feat* p);
+int fy_audio_feat_frames(const fy_audio_feat* p, int64_t n_samples);
+int fy_audio_feat_run(fy_audio_feat* p, const float* wav, int64_t n_samples, float* out, int32_t frames, uint32_t flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

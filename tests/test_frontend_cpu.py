@@ -179,3 +179,67 @@ def test_oracle_prompt_mel():
     tone = 0.5 * torch.sin(2 * torch.pi * 1000.0 * torch.arange(48000) / 24000.0).unsqueeze(0)
     mt = ofe.mel_spectrogram(tone)
     assert int(mt[0, :, 50].argmax()) == int(np.abs(hz - 1000).argmin())                         # a 1 kHz tone lands in the 1 kHz filter
+
+
+# ---- load_wav's resampler: torchaudio.transforms.Resample's default filter bank, restated (cli/frontend.py:resample) --------
+@pytest.mark.parametrize("orig,new", [(16000, 24000), (44100, 16000), (48000, 24000), (22050, 24000)])
+def test_resample_equals_the_direct_evaluation_of_the_formula(orig, new):
+    """The filter-bank / strided-convolution form against a sample-by-sample evaluation of torchaudio's published formula
+    (oracle/frontend.py:resample_direct), on a chirp: same length (ceil(new S / orig)) and the same samples to fp32 rounding."""
+    import numpy as np
+    import torch
+    from fangyan_tts_amd.cli.frontend import resample
+    from oracle.frontend import resample_direct
+    S = 1501
+    t = np.arange(S) / orig
+    x = (0.6 * np.sin(2 * np.pi * (200.0 + 1500.0 * t) * t) + 0.2 * np.sin(2 * np.pi * 3100.0 * t)).astype(np.float32)
+    y = resample(torch.from_numpy(x)[None], orig, new)
+    ref = resample_direct(x, orig, new)
+    assert y.shape == (1, -(-new * S // orig))
+    assert float(np.abs(y[0].numpy().astype(np.float64) - ref).max()) < 2e-6
+
+
+def test_resample_keeps_a_tone_and_load_wav_uses_it(tmp_path):
+    """A 440 Hz tone at 44.1 kHz comes out as the same tone at 16 kHz (interior samples, < 2e-3: the filter's pass-band ripple),
+    through load_wav on a PCM16 file: mono mean, int16 scale, then the windowed-sinc resampler."""
+    import numpy as np
+    from scipy.io import wavfile
+    from fangyan_tts_amd.cli.frontend import load_wav
+    sr, S = 44100, 22050
+    t = np.arange(S) / sr
+    tone = 0.5 * np.sin(2 * np.pi * 440.0 * t)
+    pcm = np.stack([tone, tone], axis=1)
+    path = str(tmp_path / "tone.wav")
+    wavfile.write(path, sr, (pcm * 32767.0).astype(np.int16))
+    y = load_wav(path, 16000)
+    n = -(-16000 * S // sr)
+    assert y.shape == (1, n)
+    want = 0.5 * np.sin(2 * np.pi * 440.0 * np.arange(n) / 16000.0)
+    assert float(np.abs(y[0].numpy()[200:-200] - want[200:-200]).max()) < 2e-3
+    same = load_wav(path, 44100)
+    assert same.shape == (1, S)
+
+
+def test_whisper_and_fbank_oracles_are_sane():
+    """The two restated 16 kHz feature front ends: shapes and the fixed points their definitions imply.  whisper: S // 160 frames of
+    128 bins, values within [(max - 8 + 4) / 4, (max + 4) / 4]; a 1 kHz tone peaks in the mel band around 1 kHz.  kaldi fbank:
+    1 + (S - 400) // 160 frames of 80 bins, silence gives log(float32 eps) everywhere, the filterbank's Nyquist column is zero and
+    every triangle peaks at 1 or below."""
+    import numpy as np
+    import torch
+    from oracle.frontend import kaldi_fbank, kaldi_mel_banks, slaney_mel_filterbank, whisper_log_mel
+    S = 16000
+    tone = (0.5 * torch.sin(2 * np.pi * 1000.0 * torch.arange(S) / 16000.0))[None]
+    w = whisper_log_mel(tone)
+    assert w.shape == (1, 128, S // 160)
+    assert float(w.max() - w.min()) <= 2.0 + 1e-6
+    fb = slaney_mel_filterbank(16000, 400, 128)
+    centre = int(np.argmax(fb[:, 25]))                          # bin 25 = 1000 Hz
+    assert abs(int(w[0, :, 50].argmax()) - centre) <= 1
+    f = kaldi_fbank(torch.zeros(1, 4000))
+    assert f.shape == (1 + (4000 - 400) // 160, 80)
+    assert torch.allclose(f, torch.full_like(f, float(np.log(np.finfo(np.float32).eps))))
+    kb = kaldi_mel_banks()
+    assert kb.shape == (80, 257) and float(kb[:, 256].max()) == 0.0 and float(kb.max()) <= 1.0
+    ft = kaldi_fbank(tone)
+    assert ft.shape == (98, 80) and int(ft.mean(dim=0).argmax()) == int(np.argmax(kb[:, 32]))      # bin 32 = 1000 Hz

@@ -82,3 +82,65 @@ def test_facade_with_the_real_frontend_class(tmp_path):
     bare = AutoModel(model_dir=str(tmp_path), max_tokens=160, max_prompt_tokens=64)
     with pytest.raises(RuntimeError, match="CosyVoice-BlankEN"):
         list(bare.inference_instruct2("你好", "说<|endofprompt|>", (wav[0].numpy(), 24000)))
+
+
+def speech16k(seconds, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    n = int(16000 * seconds)
+    t = torch.arange(n) / 16000.0
+    x = 0.3 * torch.sin(2 * torch.pi * 180 * t) + 0.1 * torch.sin(2 * torch.pi * 2600 * t) + 0.05 * (torch.rand(n, generator=g) * 2 - 1)
+    return (x * torch.linspace(0.3, 1.0, n)).unsqueeze(0)
+
+
+@pytest.mark.parametrize("seconds", [0.3, 2.0, 10.0, 29.9, 1.2345])
+def test_whisper_log_mel_against_oracle(seconds):
+    """The speech tokenizer's input (cli/frontend.py:97) on the GPU against the restated whisper.log_mel_spectrogram
+    (oracle/frontend.py: torch.stft as whisper calls it; parity unpinned for the library itself): (1, 128, S // 160), the normalised
+    log10 values within 1e-3 (they span a range of 2)."""
+    from fangyan_tts_amd.cli.frontend import AudioFeat
+    from oracle import frontend as ofe
+    y = speech16k(seconds)
+    ref = ofe.whisper_log_mel(y)
+    got = AudioFeat("whisper", DEV)(y).cpu()
+    assert got.shape == ref.shape == (1, 128, y.shape[1] // 160)
+    e = maxerr(got, ref)
+    note("parity_frontend.json", f"whisper_log_mel.{seconds}s.max_abs_err", e)
+    assert e < 1e-3, e
+
+
+@pytest.mark.parametrize("seconds", [0.03, 2.0, 10.0, 1.2345])
+def test_kaldi_fbank_against_oracle(seconds):
+    """The speaker embedder's input (cli/frontend.py:111-115) on the GPU against the restated kaldi.fbank (oracle/frontend.py:
+    torch.fft.rfft as torchaudio calls it): (frames, 80) log mel energies within 2e-3, with and without the mean over frames."""
+    from fangyan_tts_amd.cli.frontend import AudioFeat
+    from oracle import frontend as ofe
+    y = speech16k(seconds, seed=3)
+    ref = ofe.kaldi_fbank(y)
+    fb = AudioFeat("fbank", DEV)
+    got = fb(y).cpu()
+    assert got.shape == ref.shape == (1 + (y.shape[1] - 400) // 160, 80)
+    e = maxerr(got, ref)
+    note("parity_frontend.json", f"kaldi_fbank.{seconds}s.max_abs_err_log_domain", e)
+    assert e < 2e-3, e
+    got_m = fb(y, subtract_mean=True).cpu()
+    assert maxerr(got_m, ref - ref.mean(dim=0, keepdim=True)) < 2e-3
+    with pytest.raises(ValueError, match="too few"):
+        fb(torch.zeros(1, 399))
+
+
+def test_onnx_sessions_are_built_only_when_they_can_be(tmp_path):
+    """AutoModel builds the reference's two ONNX sessions itself when onnxruntime imports and the files are in the model directory;
+    otherwise the callables stay injectable and the first prompt-wav call says what is missing."""
+    from fangyan_tts_amd.cli.frontend import onnx_prompt_models
+    try:
+        import onnxruntime  # noqa: F401
+        have = True
+    except Exception:
+        have = False
+    tok, emb = onnx_prompt_models(str(tmp_path), DEV)          # no .onnx files there
+    assert tok is None and emb is None
+    if not have:
+        from fangyan_tts_amd.cli.frontend import CosyVoiceFrontEnd
+        fe = CosyVoiceFrontEnd(Tok(), device=DEV)
+        with pytest.raises(NotImplementedError, match="onnxruntime"):
+            fe.speech_tokenizer(torch.zeros(1, 16000))
