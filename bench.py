@@ -169,7 +169,7 @@ def dit_roofline(ms, flops, n, where, traffic):
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {"bound": "mfma", "kernel": "DiT linears: gemm256_k (LDS-DMA ring; per shape 320x256 tiles with staggered wave groups, 256x128 or 128x128 tiles on 16x16x32 MFMAs)",
             "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "HBM-side bytes per launch, mean over the DiT's products (rocprofv3 --pmc, profiles/r03_gemm_pmc.json)",
+            "traffic_unit": "HBM-side bytes per launch, mean over every gemm256_k launch of the run (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over bench.py itself, separate passes: profiles/r03_bench_pmc.json)",
             "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2), "gflop_per_launch": round(flops / max(n, 1) / 1e9, 3), "measured_over": where}
 
 
@@ -404,7 +404,7 @@ def main():
 
     where_t = (f"HIP events on the launch stream around every launch, over a repeat of the {a.steps} timed steps in the timed configuration "
                f"(pipelined: {pipelined})")
-    roofline = dit_roofline(ms_t, flops_t, n_t, where_t, _pmc("r03_gemm_pmc.json", "dit_mix_traffic_bytes_per_launch"))
+    roofline = dit_roofline(ms_t, flops_t, n_t, where_t, _pmc("r03_bench_pmc.json", "kernels", "gemm256_k", "traffic_bytes"))
     roofline["why_this_kernel"] = ("the kernel family with the largest share of GPU time in the timed region (profiles/r03_bench_kernel_stats.csv); "
                                    "bound MFMA: 2 M N K flop per launch, SURVEY 8(d)")
     roofline["one_step_alone"] = dit_roofline(ms, flops, n, "the same events over one un-pipelined step (nothing else on the GPU)", None)
@@ -432,8 +432,8 @@ def main():
     gb_a = bytes_v / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0
     roofline_lm = {"bound": "hbm", "kernel": f"LM decode products at {BATCH * G} rows per weight pass: gemv32_k (qkv, o-proj, gate/up, down of 24 layers + llm_decoder; 97 launches per token step)",
                    "achieved": round(gb_t, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gb_t / PEAK_HBM_GBPS, 4),
-                   "traffic": _pmc("r03_gemv32_pmc.json", "traffic_bytes_per_launch"),
-                   "traffic_unit": "HBM-side bytes per launch, mean over a token step (rocprofv3 --pmc, profiles/r03_gemv32_pmc.json)",
+                   "traffic": _pmc("r03_bench_pmc.json", "kernels", "gemv32_k", "traffic_bytes"),
+                   "traffic_unit": "HBM-side bytes per launch, mean over every gemv32_k launch of the run (rocprofv3 --pmc over bench.py itself: profiles/r03_bench_pmc.json); above the weights by the A images each XCD's L2 fetches once and the split-K partial tiles",
                    "launches": n_vt, "avg_launch_us": round(1e3 * ms_vt / max(n_vt, 1), 2), "algorithmic_bytes_per_launch": int(bytes_vt / max(n_vt, 1)),
                    "measured_over": where_t,
                    "one_generation_alone": {"achieved": round(gb_a, 1), "frac": round(gb_a / PEAK_HBM_GBPS, 4), "avg_launch_us": round(1e3 * ms_v / max(n_v, 1), 2), "launches": n_v,
@@ -459,8 +459,8 @@ def main():
         roofline_lm_p = {"bound": "hbm", "kernel": "llm_decode_k: one persistent launch per token step (24 layers + llm_decoder, 152 workgroups, "
                          "weights register-resident a layer ahead, 121 grid-wide hand-offs)", "achieved": round(gb, 1), "peak": PEAK_HBM_GBPS,
                          "unit": "GB/s", "frac": round(gb / PEAK_HBM_GBPS, 4),
-                         "traffic": _pmc("r03_llm_decode_pmc.json", "kernels", "llm_decode_k", "traffic_bytes") or _pmc("r02_llm_decode_pmc.json", "kernels", "llm_decode_k", "traffic_bytes"),
-                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc, profiles/r0x_llm_decode_pmc.json: kernels.llm_decode_k.traffic_bytes)",
+                         "traffic": _pmc("r03_bench_pmc.json", "kernels", "llm_decode_k", "traffic_bytes"),
+                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc over bench.py itself: profiles/r03_bench_pmc.json, kernels.llm_decode_k.traffic_bytes)",
                          "launches": n_p, "avg_launch_us": round(1e3 * ms_p / max(n_p, 1), 1), "algorithmic_bytes_per_launch": int(bytes_p / max(n_p, 1)),
                          "generate_ms_batch8_75_tokens": round(lm_p_ms, 2),
                          "measured_over": "HIP events on the launch stream around every launch of one 75-token generation at batch 8, run alone"}

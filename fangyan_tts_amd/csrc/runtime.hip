@@ -211,3 +211,38 @@ extern "C" int fy_stream_destroy(void* stream) {
     if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return FY_OK;
 }
+
+// ---- synthetic tensors (fangyan_tts_amd/synth.py; SURVEY 8c "Synthetic weights") on the device -----------------------------------
+// dst[i] = float(lo + (hi - lo) * u(seed, start + i)), u = (splitmix64 finaliser of seed + (index + 1) * golden) >> 11 scaled by
+// 2^-53 - bit for bit what synth.uniform computes in numpy (float64 arithmetic, no contraction, one rounding to float32);
+// flags bit 0: round to the nearest bf16-representable value (ties to even, synth.bf16_round); bit 1: dst = 1.0f + that (fp32 add).
+// Lets bench.py and the tests fill the 0.86 G parameters without a single torch elementwise launch.
+__global__ void synth_uniform_k(float* __restrict__ dst, long n, unsigned long long seed, long start, double lo, double hi, unsigned flags) {
+#pragma clang fp contract(off)
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        unsigned long long z = ((unsigned long long)(start + i) + 1ull) * 0x9E3779B97F4A7C15ull + seed;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z = z ^ (z >> 31);
+        const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+        const double span = hi - lo;
+        const double prod = span * u;
+        float x = (float)(lo + prod);
+        if (flags & 1u) {
+            unsigned b = __float_as_uint(x);
+            b = (b + 0x7FFFu + ((b >> 16) & 1u)) & 0xFFFF0000u;
+            x = __uint_as_float(b);
+        }
+        if (flags & 2u) x = 1.0f + x;
+        dst[i] = x;
+    }
+}
+
+extern "C" int fy_synth_uniform(float* dst, int64_t n, uint64_t seed, int64_t start, double lo, double hi, uint32_t flags, void* stream) {
+    FY_CHECK(dst && n >= 1 && start >= 0, FY_ERR_ARG, "fy_synth_uniform: bad arguments");
+    const long blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(synth_uniform_k, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, dst, (long)n,
+                       (unsigned long long)seed, (long)start, lo, hi, flags);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}

@@ -245,6 +245,45 @@ def _bf16_round_torch(x):
     return r.to(torch.int32).view(torch.float32)
 
 
+_LIB_FILL_MIN = 1 << 16        # tensors from this size on are filled by the library's kernel on a GPU device; smaller ones by numpy + a copy
+
+
+def _tensor_device(name: str, shape, device):
+    """`tensor` on a GPU without a torch kernel: the library's counter-based fill (csrc/runtime.hip:synth_uniform_k, bit-identical
+    to the numpy form) for large tensors, numpy + one host-to-device copy for small ones.  None when the library is not there."""
+    import torch
+    shape = tuple(int(s) for s in shape)
+    n = int(np.prod(shape))
+    for rx, kind, arg in _RULES:
+        if rx.search(name):
+            break
+    else:
+        raise KeyError(f"no synth rule for {name}")
+    if n < _LIB_FILL_MIN or kind == "postbias":
+        return torch.from_numpy(tensor(name, shape)).to(device)
+    import ctypes as C
+    from . import _lib
+    if kind in ("w", "wf32"):
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+        a = float(arg) * np.sqrt(3.0 / fan_in)
+        lo, hi, flags = -a, a, (1 if kind == "w" else 0)
+    elif kind == "emb":
+        lo, hi, flags = -arg, arg, 1
+    elif kind == "b":
+        lo, hi, flags = -arg, arg, 0
+    elif kind == "one":
+        lo, hi, flags = -arg, arg, 2
+    elif kind == "range":
+        lo, hi, flags = arg[0], arg[1], 0
+    else:
+        raise ValueError(kind)
+    out = torch.empty(shape, dtype=torch.float32, device=device)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.lib().fy_synth_uniform(out.data_ptr(), n, name_seed(name), 0, float(lo), float(hi), flags,
+                                               C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)))
+    return out
+
+
 def tensor_torch(name: str, shape, device="cpu"):
     """torch twin of `tensor` (whole tensors only)."""
     import torch
@@ -278,17 +317,31 @@ def tensor_torch(name: str, shape, device="cpu"):
     raise ValueError(kind)
 
 
+def _have_lib() -> bool:
+    import os
+    from . import _lib
+    return os.path.exists(_lib.LIB_PATH)
+
+
 def state_dict_torch(manifest, device="cpu", skip: Iterable[str] = ()):
     """torch twin of `state_dict`: name -> fp32 tensor on `device`."""
     import torch
     skip = tuple(skip)
     out = {}
+    on_gpu = torch.device(device).type == "cuda" and _have_lib()
     for name, shape in manifest.items():
         if any(s in name for s in skip) or name.endswith("parametrizations.weight.original0"):
             continue
-        out[name] = tensor_torch(name, shape, device)
+        if on_gpu and (name[:-1] + "0") in manifest and name.endswith("parametrizations.weight.original1"):
+            continue                                   # a weight-normed pair: below, on the host (g needs the norm of v)
+        out[name] = _tensor_device(name, shape, device) if on_gpu else tensor_torch(name, shape, device)
     for name in manifest:
         if name.endswith("parametrizations.weight.original0") and not any(s in name for s in skip):
+            if on_gpu:
+                v = tensor(name[:-1] + "1", manifest[name[:-1] + "1"])
+                out[name[:-1] + "1"] = torch.from_numpy(v).to(device)
+                out[name] = torch.from_numpy(weight_norm_g(v)).to(device)
+                continue
             v = out[name[:-1] + "1"]
             co = v.shape[0]
             nrm = torch.sqrt((v.to(torch.float64).reshape(co, -1) ** 2).sum(dim=1))

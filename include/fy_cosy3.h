@@ -231,6 +231,12 @@ int fy_audio_feat_mels(const fy_audio_feat* p);
 int fy_audio_feat_frames(const fy_audio_feat* p, int64_t n_samples);
 int fy_audio_feat_run(fy_audio_feat* p, const float* wav, int64_t n_samples, float* out, int32_t frames, uint32_t flags, void* stream);
 
+/* ================================ tooling: synthetic tensors ================================
+ * No pretrained checkpoint is reachable offline: tests and bench.py fill the model from a counter-based generator
+ * (fangyan_tts_amd/synth.py).  This is that generator's uniform draw on the device, bit-identical to the numpy form:
+ * dst[i] = float(lo + (hi - lo) * u(seed, start + i)); flags bit 0 rounds to bf16-representable values, bit 1 adds 1.0f.  */
+int fy_synth_uniform(float* dst, int64_t n, uint64_t seed, int64_t start, double lo, double hi, uint32_t flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

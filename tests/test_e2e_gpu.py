@@ -8,8 +8,8 @@ Stated tolerances, each about 3x what is measured (gpurun_out/parity_e2e.json):
     mel     max |err| <= 4e-2 against the reference fixture (measured 1.0-1.3e-2; values of scale ~1.5);
     wav     (a) max |err| <= 2.5e-3 against the oracle vocoder run on the engine's own mel (measured 5-9e-4),
             (b) max |err| <= 2e-2 against the reference fixture on the first 10 frames (measured <= 7.5e-3),
-            (c) log-mel distance to the fp32-class waveform (phase-insensitive) <= 3 dB at the reduced size, <= 6 dB at
-                full size (measured 0.4-1.1 / 2.4-4.6; a random-weight vocoder is that sensitive: uniform +-1e-2 noise on
+            (c) log-mel distance to the fp32-class waveform (phase-insensitive) <= 3 dB at the reduced size, <= 1.5 x the
+                measured value per full-size case (3.2 / 4.4 / 6.2 dB for measured 2.1 / 2.9 / 4.2; a random-weight vocoder is that sensitive: uniform +-1e-2 noise on
                 the mel alone moves the oracle's waveform by 2.7 dB);
   fp32-class mode (FY_PRECISE flow + FY_DIRECT vocoder):
     mel     max |err| <= 6e-5 against the reference fixture (measured 1.5-1.8e-5);
@@ -166,11 +166,12 @@ def test_full_size_against_reference_fixture():
     wav, samples, toks = m.tts_batch([inp])
     assert toks[0].cpu().tolist() == f[f"c{ctag}.tokens"].tolist()
     wav_checks(m, cfg, sd[2], wav, samples[0], f, ctag, ri, sn, "full")
-    whole_wav_checks(m, cfg, sd, inp, f, ctag, ri, sn, "full", 6e-5, 1.5e-3, 6.0)
+    whole_wav_checks(m, cfg, sd, inp, f, ctag, ri, sn, "full", 6e-5, 1.5e-3, 3.2)          # measured 2.1 dB
 
 
-@pytest.mark.parametrize("case,name", [((14, 8, 0, 125), "config1_instruct"), ((14, 30, 250, 250), "config3_zero_shot")])
-def test_configuration_sizes_against_reference_fixture(case, name):
+# log-mel bound per case = 1.5 x the measured distance (2.9 and 4.2 dB: gpurun_out/parity_e2e.json)
+@pytest.mark.parametrize("case,name,logmel_db", [((14, 8, 0, 125), "config1_instruct", 4.4), ((14, 30, 250, 250), "config3_zero_shot", 6.2)])
+def test_configuration_sizes_against_reference_fixture(case, name, logmel_db):
     """BASELINE.json configs 1 and 3 at their real sizes - instruct: 8 + 14 text ids behind a 5 s prompt; zero-shot: 30
     prompt-text ids, 250 prompt speech tokens in the LM (a 296-row prefill) and 10 s of prompt mel (DiT sequence 500 + 2n) -
     against fixtures minted from the reference's CosyVoice3Model.tts with its own stopping rule: ids exact, mel, waveform."""
@@ -193,7 +194,7 @@ def test_configuration_sizes_against_reference_fixture(case, name):
     note("parity_e2e.json", f"{name}.tokens", [len(got), len(ref), first_bad])
     assert got == ref, (len(got), len(ref), first_bad)
     wav_checks(m, cfg, sd[2], wav, samples[0], f, ctag, ri, sn, name)
-    whole_wav_checks(m, cfg, sd, inp, f, ctag, ri, sn, name, 6e-5, 1.5e-3, 6.0)
+    whole_wav_checks(m, cfg, sd, inp, f, ctag, ri, sn, name, 6e-5, 1.5e-3, logmel_db)
 
 
 def test_pipeline_equals_batches(tiny):
