@@ -32,7 +32,7 @@ __device__ __forceinline__ gv_frag gv32_ld(const bf16_t* p) {
 
 template <int NT, int NW, int DB>
 __global__ __launch_bounds__(NW * 64) void gemv32_k(const Gv32Args a) {
-    __shared__ __attribute__((aligned(16))) float red[NW * NT * 16 * 64];
+    extern __shared__ __attribute__((aligned(16))) float red[];          // [NW][NT][16][64]: the waves' accumulators (dynamic: 64 KB at NT = 4)
     __shared__ float rstd_s[32];
     __shared__ int s_last;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -246,12 +246,15 @@ int gemv32(const Gv32Args& a, hipStream_t st) {
     static const int ks_down = gv32_env("FY_GV32_KS", 8), nt2_from = gv32_env("FY_GV32_NT2_FROM", 257), nw8_below = gv32_env("FY_GV32_NW8_BELOW", 128);
     int KS = 1;
     if (a.K >= 2048 && a.partial && a.counters) KS = std::min(std::max(1, ks_down), GV32_KS_MAX);
+    auto lds_of = [](int nt, int nw) { return (size_t)nw * nt * 16 * 64 * sizeof(float); };
+    // (four tiles per block - the A image read once per 128 columns - measured slower: 14.0 / 29.1 us against 11.5 / 12.9 for
+    // gate/up and down alone, 63.0 against 61.6 ms per pipelined step)
     if (tiles >= nt2_from && KS == 1) {
-        hipLaunchKernelGGL((gemv32_k<2, 4, 7>), dim3(cdiv(tiles, 2), 1, Z), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemv32_k<2, 4, 7>), dim3(cdiv(tiles, 2), 1, Z), dim3(256), lds_of(2, 4), st, a);
     } else if (tiles < nw8_below && KS == 1) {
-        hipLaunchKernelGGL((gemv32_k<1, 8, 7>), dim3(tiles, 1, Z), dim3(512), 0, st, a);
+        hipLaunchKernelGGL((gemv32_k<1, 8, 7>), dim3(tiles, 1, Z), dim3(512), lds_of(1, 8), st, a);
     } else {
-        hipLaunchKernelGGL((gemv32_k<1, 4, 7>), dim3(tiles, KS, Z), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((gemv32_k<1, 4, 7>), dim3(tiles, KS, Z), dim3(256), lds_of(1, 4), st, a);
     }
     HIP_TRY(hipGetLastError());
     return FY_OK;
