@@ -257,6 +257,40 @@ def bench_latency_b1(cfg, sd_llm, sd_flow, sd_hift, dev, inputs, reps=4):
     return out
 
 
+def bench_first_chunk(cfg, sd_llm, sd_flow, sd_hift, dev, inputs, reps=3):
+    """stream=True on one utterance (5 s prompt): wall time from the call to the first audio chunk on the host - the figure the
+    reference quotes as "latency as low as 150 ms" (CosyVoice/README.md:19) - and to the last one.  The LM is stepped on demand
+    (persistent token step), the first chunk leaves after hop + look-ahead = 28 tokens (the 125 prompt tokens are a multiple of the
+    hop of 25), flow decoder with the chunk mask over prompt + 28 tokens, vocoder over the 50 valid frames minus its look-ahead."""
+    from fangyan_tts_amd import synth
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    n_max = 20 * 20
+    m = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=1, max_text=64, max_prompt_tokens=P_TOK, max_tokens=n_max,
+                        rand_noise=torch.from_numpy(synth.flow_rand_noise(2 * (P_TOK + n_max))).to(dev),
+                        rand_ini=torch.from_numpy(synth.hift_rand_ini()).to(dev),
+                        sine_noise=torch.from_numpy(synth.hift_sine_noise(2 * n_max * 480)).to(dev))
+    one = inputs[0]
+    list(m.tts(**one, stream=True))
+    torch.cuda.synchronize()
+    first, total, chunks, audio = [], [], 0, 0.0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        g = m.tts(**one, stream=True)
+        c0 = next(g)["tts_speech"]
+        t1 = time.perf_counter()
+        rest = [c["tts_speech"] for c in g]
+        t2 = time.perf_counter()
+        first.append(t1 - t0); total.append(t2 - t0)
+        chunks, audio = 1 + len(rest), (c0.shape[1] + sum(r.shape[1] for r in rest)) / 24000.0
+    out = {"workload": "one utterance, stream=True, 5 s prompt, the LM's own stopping rule (random-init weights)", "first_chunk_ms": round(1e3 * sorted(first)[len(first) // 2], 2),
+           "first_chunk_audio_s": round(c0.shape[1] / 24000.0, 3), "all_chunks_ms": round(1e3 * sorted(total)[len(total) // 2], 2), "chunks": chunks,
+           "audio_s": round(audio, 2), "reference_claim": "latency as low as 150 ms (CosyVoice/README.md:19, other hardware)"}
+    m.close()
+    del m
+    torch.cuda.empty_cache()
+    return out
+
+
 def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -273,6 +307,7 @@ def main():
     ap.add_argument("--lm-isolate", action="store_true", help="LM streams run ONLY on the CUs the flow stream is kept off")
     ap.add_argument("--lm-group", type=int, default=4, help="consecutive steps whose LM decode runs as one call (32 rows per weight pass)")
     ap.add_argument("--flow-cu-exclude", type=int, default=0, help="CUs kept clear of the flow / vocoder stream")
+    ap.add_argument("--flow-workers", type=int, default=2, help="consecutive steps whose flow decoder + vocoder run side by side (own handles and streams)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -318,7 +353,8 @@ def main():
     pipelined = not a.no_pipeline
     n_llm, group = (a.llm_streams, a.lm_group) if pipelined else (1, 1)
     model = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=BATCH, max_text=64, max_prompt_tokens=P_TOK,
-                            max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn, n_llm=n_llm, lm_group=group)
+                            max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn, n_llm=n_llm, lm_group=group,
+                            flow_workers=a.flow_workers if pipelined else 1)
     if pipelined:
         model.prepare_pipeline(a.flow_cu_exclude)        # stream placement on the hardware pipes: set-up, not part of a step
     log("engines ready")
@@ -492,10 +528,10 @@ def main():
         "config": {"workload": "CosyVoice3-0.5B instruct (inference_instruct2), batch 8 mixed-length utterances per GPU, "
                                "5 s prompt, 75 forced speech tokens (3 s) each, LM greedy -> 10-step CFG flow (DiT-22) -> HiFT",
                    "batch_per_gpu": BATCH, "tokens_per_utt": N_TOK, "prompt_tokens": P_TOK, "parallelism": f"dp{world}",
-                   "steps_pipelined": pipelined, "llm_streams": n_llm, "lm_group": group,
+                   "steps_pipelined": pipelined, "llm_streams": n_llm, "lm_group": group, "flow_workers": a.flow_workers if pipelined else 1,
                    "lm_rows_per_weight_pass": BATCH * group,
-                   "utterances_in_flight_max": BATCH * (3 * group * n_llm + 1) if pipelined else BATCH,
-                   "in_flight_note": "one LM call decodes lm_group steps' batches together; the ids of up to 2 x lm_group finished batches wait in a queue; one batch is in the flow decoder / vocoder",
+                   "utterances_in_flight_max": BATCH * (3 * group * n_llm + a.flow_workers) if pipelined else BATCH,
+                   "in_flight_note": "one LM call decodes lm_group steps' batches together; the ids of up to 2 x lm_group finished batches wait in a queue; flow_workers batches are in the flow decoder / vocoder side by side",
                    "flow_cu_exclude": a.flow_cu_exclude, "batch_latency_ms_unpipelined": round(latency_ms, 1),
                    "weights": "random-init, CosyVoice3-0.5B shapes (859 M params)"},
         # the strict batch-8 figure: one batch at a time, nothing of another batch in flight (tts_batch; LM on the persistent step)
@@ -509,6 +545,8 @@ def main():
         # behind the timed region: BASELINE.json configs[0], configs[2] and configs[4] as secondary objects of the same record
         log("one utterance alone (config 1's shape)")
         out["latency_b1"] = bench_latency_b1(cfg, sd_llm, sd_flow, sd_hift, dev, inputs)
+        log("first streaming chunk")
+        out["first_chunk"] = bench_first_chunk(cfg, sd_llm, sd_flow, sd_hift, dev, inputs)
         log("zero-shot batch 4 (config 3)")
         out["zero_shot_b4"] = bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib)
         log("HiFT-only 32 x 10 000 frames (config 5)")

@@ -32,7 +32,7 @@ class CosyVoice3Model:
                  max_batch: int = 8, max_text: int = 128, max_prompt_tokens: int = 800, max_tokens: int = 800,
                  rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
                  sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False, n_llm: int = 1,
-                 sampler: str = "greedy", sampler_seed: int = 1986, lm_group: int = 1, concurrency: int = 1):
+                 sampler: str = "greedy", sampler_seed: int = 1986, lm_group: int = 1, concurrency: int = 1, flow_workers: int = 1):
         if not torch.cuda.is_available():
             raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -70,6 +70,13 @@ class CosyVoice3Model:
         self._free = _q.Queue()
         for ln in self.lanes:
             self._free.put(ln)
+        # flow_workers > 1: tts_pipeline runs the flow decoder + vocoder of that many consecutive batches at once, each on its own
+        # (flow, vocoder) handle pair and stream: one batch's launch tails, epilogue bursts and whole-tile round-up (a third of a DiT
+        # product's time) overlap the other batch's K loops
+        self._flow_sets = [_Lane(None, self.flow, self.hift, None)]
+        for _ in range(1, max(1, flow_workers)):
+            self._flow_sets.append(_Lane(None, FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device),
+                                         HiftEngine(hift_weights, cfg.hift, max_batch=max_batch, max_frames=2 * max_tokens, device=self.device), None))
         # `model.llm.load_state_dict` (compare_inference.py:42 swaps a fine-tuned LM in) must reach every LM handle
         self.llm._peers = [e for e in self.llms[1:]] + [ln.llm for ln in self.lanes[1:]]
         self._count_mu = threading.Lock()
@@ -238,13 +245,11 @@ class CosyVoice3Model:
         flow decoder + vocoder of batch i (throughput-bound).  Yields (wav, n_samples, tokens) per batch, in
         order.  Same results as tts_batch.
 
-        flow_cu_exclude: CUs the flow / vocoder stream may NOT use (hipExtStreamCreateWithCUMask).  Measured on MI355X at
-        batch 8 with three LM handles and all streams on their own hardware pipes (`_pipe_streams`): 84.0 ms per step with no
-        mask, 84.1 / 84.2 with 16 / 32 CUs kept clear, 91.9 with 64 - the LM's short kernels are not waiting for CUs, they
-        are stretched by the memory traffic of the GEMMs beside them.  With ONE LM handle 80 clear CUs helped (137 -> 126 ms).
-        None = 80 for one handle, 0 (no mask) otherwise.
-        lm_isolate additionally confines the LM streams to the excluded CUs (complementary masks); measured slower at every
-        split: the decode kernels want the whole chip for their short bursts.
+        flow_cu_exclude: CUs the flow / vocoder stream may NOT use (hipExtStreamCreateWithCUMask); None = 0 = no mask.  Measured on
+        MI355X at batch 8 (round 3, one LM handle decoding four batches per call): 60.6 ms per step with no mask, 70.6 / 74.5 / 75.1
+        with 8 / 16 / 32 CUs kept clear, 82.7 with 80 - a masked stream is slower by itself and the LM's short kernels do not wait
+        for whole CUs.  lm_isolate additionally confines the LM streams to the excluded CUs (complementary masks); measured slower
+        at every split (round 2: 126-197 ms).
         Set FY_PIPE_TRACE=1 for per-stage wall times on stderr."""
         import os
         import queue
@@ -255,9 +260,11 @@ class CosyVoice3Model:
         dev = self.device
         n_prod = len(self.llms)
         if flow_cu_exclude is None:
-            flow_cu_exclude = 80 if n_prod == 1 else 0
-        pool = self._pipe_streams(1 + n_prod, flow_cu_exclude)
-        s_fv = pool[0]
+            flow_cu_exclude = 0
+        n_fl = len(self._flow_sets)
+        assert n_fl == 1 or not flow_cu_exclude, "a CU-masked flow stream exists once: use flow_workers=1 with flow_cu_exclude"
+        pool = self._pipe_streams(n_fl + n_prod, flow_cu_exclude)
+        flow_streams, lm_streams = pool[:n_fl], pool[n_fl:]
         qs = [queue.Queue(maxsize=2 * self.lm_group) for _ in range(n_prod)]
         z = torch.zeros(1, 0, dtype=torch.int32)
         stop, box = th.Event(), {}
@@ -276,7 +283,7 @@ class CosyVoice3Model:
         def producer(pi):
             llm, q = self.llms[pi], qs[pi]
             try:
-                lm_stream = self._masked_stream(flow_cu_exclude, only=True, tag=pi) if (flow_cu_exclude > 0 and lm_isolate) else pool[1 + pi]
+                lm_stream = self._masked_stream(flow_cu_exclude, only=True, tag=pi) if (flow_cu_exclude > 0 and lm_isolate) else lm_streams[pi]
                 with torch.cuda.device(dev), torch.cuda.stream(lm_stream):
                     G = self.lm_group
                     for g0 in range(pi * G, len(batches), n_prod * G):
@@ -306,7 +313,69 @@ class CosyVoice3Model:
             except BaseException as e:                             # surfaces in the consumer
                 put(q, e)
 
+        n_flow = len(self._flow_sets)
+        work_q = [queue.Queue() for _ in range(n_flow)]
+        res_q = [queue.Queue(maxsize=2) for _ in range(n_flow)]          # a worker enqueues at most two batches ahead of the consumer
+
+        def take(q):
+            while not stop.is_set():
+                try:
+                    return q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            return None
+
+        def feeder():
+            # ids arrive in batch order from the producers' queues; batch bi goes to flow worker bi % n_flow
+            for bi in range(len(batches)):
+                item = take(qs[(bi // self.lm_group) % n_prod])
+                if item is None:
+                    return
+                work_q[bi % n_flow].put((bi, item, time.perf_counter()))
+                if isinstance(item, BaseException):
+                    return
+
+        def worker(w):
+            fs, st = self._flow_sets[w], flow_streams[w]
+            try:
+                with torch.cuda.device(dev):
+                    for bi in range(w, len(batches), n_flow):
+                        got = take(work_q[w])
+                        if got is None:
+                            return
+                        _, item, t1 = got
+                        if isinstance(item, BaseException):
+                            res_q[w].put(item)
+                            return
+                        inputs, out, n_tok = item
+                        if min(n_tok) < 1:
+                            raise RuntimeError("the language model emitted no speech token for an utterance")
+                        # The worker waits for its batch before it takes the next one.  Measured against running ahead (the batch's
+                        # completion as an event for the consumer's stream, the next batch enqueued behind it at once - possible
+                        # since neither engine call synchronises the stream any more: their length tables ride in kernel
+                        # arguments): 61.4 ms per step with the wait against 62.7 without (one worker), 59.4 against 59.6 (two).
+                        # (Holes of 8-13 ms that rocprofv3 --kernel-trace shows on the flow queue between two batches stay when
+                        # the launches are enqueued ahead: the profiler's stream placement, not the host - DESIGN.md section 10.)
+                        with torch.cuda.stream(st):
+                            wav, samples = self._token2wav(inputs, out, n_tok, 1.0, fs)
+                            mel, frames = self.last_mel_of[id(fs)]
+                            t2 = time.perf_counter()
+                            if keep_on_device:
+                                res, ev = wav, torch.cuda.Event()
+                                ev.record(st)
+                                st.synchronize()
+                            else:
+                                res, ev = wav.cpu(), None
+                        if trace:
+                            print(f"[pipe] batch {bi} (flow worker {w}): launches enqueued {1e3 * (t2 - t1):.1f} ms after its ids arrived",
+                                  file=sys.stderr)
+                        if not put(res_q[w], (res, samples, [out[b, : n_tok[b]] for b in range(len(inputs))], mel, frames, ev)):
+                            return
+            except BaseException as e:                            # surfaces in the consumer
+                res_q[w].put(e)
+
         threads = [th.Thread(target=producer, args=(i,), daemon=True) for i in range(n_prod)]
+        threads += [th.Thread(target=feeder, daemon=True)] + [th.Thread(target=worker, args=(w,), daemon=True) for w in range(n_flow)]
         with self._take_all_lanes():
             was_persistent = [e.persistent for e in self.llms]
             for e in self.llms:
@@ -316,31 +385,29 @@ class CosyVoice3Model:
                 t.start()
             try:
                 for bi in range(len(batches)):
-                    t0 = time.perf_counter()
-                    item = qs[(bi // self.lm_group) % n_prod].get()
-                    t1 = time.perf_counter()
-                    if isinstance(item, BaseException):
-                        raise item
-                    inputs, out, n_tok = item
-                    if min(n_tok) < 1:
-                        raise RuntimeError("the language model emitted no speech token for an utterance")
-                    with torch.cuda.stream(s_fv):
-                        wav, samples = self._token2wav(inputs, out, n_tok, 1.0)
-                        t2 = time.perf_counter()
-                        res = (wav if keep_on_device else wav.cpu())
-                    s_fv.synchronize()
-                    if trace:
-                        print(f"[pipe] batch {bi}: waited {1e3 * (t1 - t0):.1f} ms for ids, flow+vocoder {1e3 * (time.perf_counter() - t1):.1f} ms "
-                              f"(its launches were enqueued after {1e3 * (t2 - t1):.1f} ms)", file=sys.stderr)
-                    # yielded OUTSIDE the stream context: the caller's own torch work (an all-gather, a copy) stays on its stream
-                    yield res, samples, [out[b, : n_tok[b]] for b in range(len(inputs))]
+                    r = None
+                    while r is None:
+                        try:
+                            r = res_q[bi % n_flow].get(timeout=0.5)
+                        except queue.Empty:
+                            if not any(t.is_alive() for t in threads[n_prod + 1:]):
+                                raise RuntimeError("tts_pipeline: the flow workers ended without a result")
+                    if isinstance(r, BaseException):
+                        raise r
+                    res, samples, toks, mel, frames, ev = r
+                    if ev is not None:                                 # the caller's stream waits for the batch, not the host
+                        torch.cuda.current_stream(dev).wait_event(ev)
+                    self.last_mel, self.last_frames = mel, frames      # of the batch being handed out
+                    # yielded on the caller's thread and stream: its own torch work (an all-gather, a copy) stays on its stream
+                    yield res, samples, toks
             finally:
-                # an abandoned or failed generator must not leave producers inside the single-threaded LM handles: tell them
-                # to stop, empty the queues so none stays parked in put(), and join them before the lock is released
+                # an abandoned or failed generator must not leave producers inside the single-threaded LM handles (or workers inside
+                # the flow handles): tell them to stop, empty the queues so none stays parked in put(), and join them before the lock
+                # is released
                 stop.set()
                 for t in threads:
                     while t.is_alive():
-                        for q in qs:
+                        for q in qs + work_q + res_q:
                             try:
                                 while True:
                                     q.get_nowait()
@@ -354,8 +421,8 @@ class CosyVoice3Model:
         """Place the pipeline's streams now (otherwise the first tts_pipeline call does it, ~0.1-0.4 s)."""
         n_prod = len(self.llms)
         if flow_cu_exclude is None:
-            flow_cu_exclude = 80 if n_prod == 1 else 0
-        self._pipe_streams(1 + n_prod, flow_cu_exclude)
+            flow_cu_exclude = 0
+        self._pipe_streams(len(self._flow_sets) + n_prod, flow_cu_exclude)
 
     def _pipe_streams(self, n: int, flow_exclude: int = 0):
         """The streams of the pipeline (flow + vocoder first, then one per LM handle), chosen once per model so that they are
@@ -474,6 +541,7 @@ class CosyVoice3Model:
             frames = [mel.shape[2]]
         wav, _ = ln.hift.inference(mel, self.rand_ini, self.sine_noise, frames=frames, flags=self.hift_flags)
         self.last_mel, self.last_frames = mel, frames        # kept for parity tests / debugging
+        self.__dict__.setdefault("last_mel_of", {})[id(ln)] = (mel, frames)       # per handle set: tts_pipeline's flow workers run side by side
         return wav, [f * self.cfg.hift.upsample_total for f in frames]
 
     # ------------------------------------------------------------------ stream=True (cli/model.py:339-369, 416-441)

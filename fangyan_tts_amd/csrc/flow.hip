@@ -539,9 +539,9 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
         sl[2 * b] = sl[2 * b + 1] = T;
         Tmax = std::max(Tmax, T); Nmax = std::max(Nmax, n_all);
     }
-    HIP_TRY(hipMemcpyAsync(f->blen, lens.data(), lens.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(f->seq_len, sl.data(), sl.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    // by kernel argument, not by copy + synchronisation: the call can be enqueued behind a previous one that is still running
+    FY_TRY(upload_ints(f->blen, lens.data(), (int)lens.size(), st));
+    FY_TRY(upload_ints(f->seq_len, sl.data(), (int)sl.size(), st));
     const int *d_nall = f->blen, *d_T = f->blen + mb, *d_pmel = f->blen + 2 * mb, *d_np = f->blen + 3 * mb, *d_nout = f->blen + 4 * mb;
     // front: speaker projection, token embedding, PreLookahead (upsample_encoder.py:82-103)
     hipLaunchKernelGGL(spk_k, dim3(B), dim3(256), 0, st, embedding, f->spk_w, f->spk_b, f->spks, c.spk_in, C);

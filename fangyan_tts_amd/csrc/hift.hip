@@ -424,8 +424,7 @@ static int set_lens(fy_hift* h, const int32_t* frames, int B, int Fmax, hipStrea
         v[6 * mb + b] = Ff0;
         v[7 * mb + b] = Fd;
     }
-    HIP_TRY(hipMemcpyAsync(h->lens, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));       // v goes out of scope
+    FY_TRY(upload_ints(h->lens, v.data(), (int)v.size(), st));      // by kernel argument: no stream synchronisation (runtime.h)
     h->B = B; h->Fmax = Fmax;
     return init_tables();
 }

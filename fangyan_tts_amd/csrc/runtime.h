@@ -37,6 +37,11 @@ struct DevPool {
     }
 };
 
+// n host ints -> device memory WITHOUT a copy engine or a stream synchronisation: the values ride in the kernel arguments of tiny
+// launches (256 per launch), so the host buffer may die at once and the caller's stream never waits for the host - a call
+// (fy_flow_infer, fy_hift_infer) can be enqueued behind a previous call that is still running (tts_pipeline does that).
+int upload_ints(int* dst, const int* src, int n, hipStream_t st);
+
 // (B, C, L) -> (B, L, C) with per-batch strides in elements
 int transpose_bcl_to_blc(const float* src, float* dst, int B, int C, int L, long src_bs, long dst_bs, int dst_ld, hipStream_t st);
 int transpose_blc_to_bcl(const float* src, float* dst, int B, int C, int L, long src_bs, int src_ld, long dst_bs, int dst_ld, hipStream_t st);

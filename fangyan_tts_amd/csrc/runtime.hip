@@ -246,3 +246,21 @@ extern "C" int fy_synth_uniform(float* dst, int64_t n, uint64_t seed, int64_t st
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
+
+// ---- small integer tables by kernel argument (runtime.h) -------------------------------------------------------------------------
+struct IntPack { int v[256]; };
+__global__ void upload_ints_k(int* __restrict__ dst, IntPack p, int n) {
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = p.v[i];
+}
+int upload_ints(int* dst, const int* src, int n, hipStream_t st) {
+    FY_CHECK(dst && src && n >= 0, FY_ERR_ARG, "upload_ints: bad arguments");
+    for (int o = 0; o < n; o += 256) {
+        IntPack p;
+        const int m = n - o < 256 ? n - o : 256;
+        memcpy(p.v, src + o, (size_t)m * sizeof(int));
+        hipLaunchKernelGGL(upload_ints_k, dim3(1), dim3(256), 0, st, dst + o, p, m);
+    }
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
