@@ -107,6 +107,24 @@ def test_many_rows_per_weight_pass(size, n_rows):
         eng.close()
 
 
+def test_eight_row_products_equal_the_32_row_products(monkeypatch):
+    """FY_LLM_GEMV32=0 keeps the 8-row products of gemm.hip on the per-operation path (operands staged and split in every block,
+    one weight pass per 8 rows): same ids and first log-probabilities as the 32-row products, tiny and full size."""
+    for size, cases, cap in (("tiny", [(12, 8, 0), (10, 6, 30)], None), ("full", [(12, 8, 0), (14, 10, 40)], 24)):
+        f = golden(f"llm_{size}.npz")
+        if f is None:
+            continue
+        cfg = LlmCfg.tiny() if size == "tiny" else LlmCfg()
+        monkeypatch.setenv("FY_LLM_GEMV32", "0")
+        eng = make(cfg, max_batch=2, max_ctx=256)
+        monkeypatch.delenv("FY_LLM_GEMV32")
+        try:
+            eng.set_decode_mode(False)
+            run_cases(eng, f, cases, cap, f"{size}.gemv8")
+        finally:
+            eng.close()
+
+
 def test_tiny_solo_equals_batched(tiny):
     f = golden("llm_tiny.npz")
     run_cases(tiny, f, [(10, 6, 30)], None, "tiny_solo")
