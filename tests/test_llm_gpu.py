@@ -116,7 +116,7 @@ def test_eight_row_products_equal_the_32_row_products(monkeypatch):
             continue
         cfg = LlmCfg.tiny() if size == "tiny" else LlmCfg()
         monkeypatch.setenv("FY_LLM_GEMV32", "0")
-        eng = make(cfg, max_batch=2, max_ctx=256)
+        eng = make(cfg, max_batch=2, max_ctx=512 if size == "tiny" else 256)
         monkeypatch.delenv("FY_LLM_GEMV32")
         try:
             eng.set_decode_mode(False)
