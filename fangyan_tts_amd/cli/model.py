@@ -524,9 +524,10 @@ class CosyVoice3Model:
         emb = torch.cat([d["flow_embedding"].reshape(1, -1) for d in inputs]).float()
         val = (ptok.to(self.device), [len(t) for t in fp], pfeat.to(self.device), [f.shape[0] for f in pf], emb.to(self.device))
         torch.cuda.current_stream(self.device).synchronize()     # the copies are complete before another stream may use them
-        if len(cache) >= 16:
-            cache.pop(next(iter(cache)))
-        cache[key] = ([(d["flow_prompt_speech_token"], d["prompt_speech_feat"], d["flow_embedding"]) for d in inputs], val)
+        with self._count_mu:                                      # tts_pipeline's flow workers share the cache
+            if len(cache) >= 16:
+                cache.pop(next(iter(cache)), None)
+            cache[key] = ([(d["flow_prompt_speech_token"], d["prompt_speech_feat"], d["flow_embedding"]) for d in inputs], val)
         return val
 
     def _token2wav(self, inputs, out, n_tok, speed, ln=None):
