@@ -195,3 +195,24 @@ def test_instruct_batch8_full_size_against_oracle():
         note("parity_configs.json", f"instruct_b8_full.{b}", [e_mel, e_wav])
         assert e_mel <= 4e-2 and e_wav <= 2.5e-3, (b, e_mel, e_wav)
     m.close()
+
+
+def test_bench_two_ranks_on_one_gpu_rehearsal():
+    """BASELINE.json configs[3]'s launch path (`bench.py --gpus N`: self-started ranks, per-rank pipelines, one fused all-gather of
+    the finished audio per step, max-over-ranks timing) rehearsed with two ranks that share this box's one GPU over gloo
+    (FY_BENCH_REHEARSAL=1: the path, not a measurement): rank 0 prints one JSON line that says n_gpus 2 and carries the
+    aggregate of both ranks."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FY_BENCH_REHEARSAL="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "4", "--no-extras", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    # 2 ranks x 8 utterances x 3 s per step
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 8 * 3.0) < 1e-3
