@@ -226,6 +226,32 @@ def test_pipeline_two_lm_handles(tiny):
             assert maxerr(w[b, : s[b]], w2[b, : s2[b]]) < 1e-5
 
 
+@pytest.mark.parametrize("sampler", ["greedy", "ras"])
+def test_pipeline_groups_of_batches_in_one_lm_call(sampler):
+    """The benchmark's configuration in miniature: ONE LM call decodes the batches of `lm_group` consecutive steps together (more
+    than 8 rows per weight pass: gemv32.hip), two flow workers run side by side - and every batch is what tts_batch returns for it
+    (ids identical, waveform <= 1e-5), under the greedy rule and under repetition-aware sampling (a batch's uniforms are seeded by
+    its batch counter, wherever it is decoded)."""
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    cfg = ModelCfg.tiny()
+    sd = [synth.state_dict_torch(mm.manifest(), DEV, skip=("lm_head",)) for mm in (cfg.llm, cfg.flow, cfg.hift)]
+    kw = dict(device=DEV, max_batch=4, max_text=32, max_prompt_tokens=32, max_tokens=160, sampler=sampler, sampler_seed=11)
+    a = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, **kw)
+    b = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, lm_group=3, flow_workers=2, **kw)
+    b.rand_noise, b.rand_ini, b.sine_noise = a.rand_noise, a.rand_ini, a.sine_noise
+    ins = [e2e_input(cfg, *c)[0] for c in CASES]
+    batches = [[ins[0], ins[1], ins[0], ins[1]], [ins[1]], [ins[1], ins[0], ins[0]], [ins[0]], [ins[0], ins[1]], [ins[1], ins[1]], [ins[0]]]
+    ref = [a.tts_batch(x) for x in batches]
+    got = list(b.tts_pipeline(batches))
+    assert len(got) == len(ref)
+    for i, ((w, s, t), (w2, s2, t2)) in enumerate(zip(got, ref)):
+        assert s == s2 and all(torch.equal(x, y) for x, y in zip(t, t2)), i
+        for k in range(len(s)):
+            assert maxerr(w[k, : s[k]], w2[k, : s2[k]]) < 1e-5, (i, k)
+    assert b.llm.persistent == a.llm.persistent          # the pipeline gave the handle its decode mode back
+    a.close(); b.close()
+
+
 def test_pipeline_abandoned_then_reused(tiny):
     """A tts_pipeline generator dropped after its first item stops its producers before the engine handles are released:
     the next call on the same model is correct (no producer still driving an LM handle)."""
