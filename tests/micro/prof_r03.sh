@@ -3,6 +3,7 @@
 #   pmc     HBM-side traffic by PMC over bench.py ITSELF (FETCH_SIZE and WRITE_SIZE in separate passes, one HSA runtime in the
 #           process: DESIGN.md section 6); the synthetic weights are filled by the library's own kernel (fy_synth_uniform), so the
 #           process launches none of the torch int64 elementwise kernels the profiler died under in rounds 1-2
+#   mfma    MFMA-busy fraction per kernel (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / 4) over bench.py itself
 #   lmpmc   the same counters over tests/micro/pmc_lm_probe.py (LM decode alone: persistent at 8 rows, per-operation at 32 rows)
 # Summaries land in gpurun_out/ (copy the ones to keep into profiles/).
 R=$GRAFT_REPO_ROOT
@@ -44,6 +45,14 @@ pmc)
     python3 $R/tests/micro/pmc_aggregate.py /tmp/pmc_bench_FETCH_SIZE /tmp/pmc_bench_WRITE_SIZE $O/r03_bench_pmc.json "rocprofv3 --pmc over bench.py --no-cpu-baseline --no-extras --steps 8 --warmup 4 itself (the default pipelined configuration), FETCH_SIZE and WRITE_SIZE in separate passes"
     echo "[prof] bench.py PMC done"
   fi
+  ;;
+mfma)
+  export LD_LIBRARY_PATH=/opt/rocm/lib LD_PRELOAD="libamdhip64.so libhsa-runtime64.so"
+  rm -rf /tmp/pmc_bench_mfma
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_bench_mfma -- python3 $R/bench.py --no-cpu-baseline --no-extras --steps 8 --warmup 4 > $O/r03_bench_under_pmc_mfma.json 2> $O/r03_pmc_bench_mfma.err || { echo "[prof] bench.py under --pmc (MFMA busy) FAILED"; tail -12 $O/r03_pmc_bench_mfma.err; }
+  unset LD_PRELOAD LD_LIBRARY_PATH
+  python3 $R/tests/micro/pmc_mfma_aggregate.py /tmp/pmc_bench_mfma $O/r03_bench_mfma_busy.json "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES over bench.py --no-cpu-baseline --no-extras --steps 8 --warmup 4 (the default pipelined configuration)"
+  echo "[prof] MFMA busy done"
   ;;
 lmpmc)
   export LD_LIBRARY_PATH=/opt/rocm/lib LD_PRELOAD="libamdhip64.so libhsa-runtime64.so"
