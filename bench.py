@@ -310,6 +310,8 @@ def main():
     ap.add_argument("--flow-workers", type=int, default=1, help="consecutive steps whose flow decoder + vocoder run side by side (own handles and streams); "
                     "2 is 3 %% faster (59.4 against 61.4 ms per step) but two DiT products then share the chip, so a launch's duration no longer "
                     "measures the kernel: the default keeps the roofline objects meaningful")
+    ap.add_argument("--flow-group", type=int, default=1, help="consecutive steps whose batches go through the flow decoder + vocoder as ONE ragged batch "
+                    "(not the default: the metric's step is a batch of 8; see DESIGN.md section 10)")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -356,7 +358,7 @@ def main():
     n_llm, group = (a.llm_streams, a.lm_group) if pipelined else (1, 1)
     model = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=BATCH, max_text=64, max_prompt_tokens=P_TOK,
                             max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn, n_llm=n_llm, lm_group=group,
-                            flow_workers=a.flow_workers if pipelined else 1)
+                            flow_workers=a.flow_workers if pipelined else 1, flow_group=a.flow_group if pipelined else 1)
     if pipelined:
         model.prepare_pipeline(a.flow_cu_exclude)        # stream placement on the hardware pipes: set-up, not part of a step
     log("engines ready")
@@ -530,7 +532,7 @@ def main():
         "config": {"workload": "CosyVoice3-0.5B instruct (inference_instruct2), batch 8 mixed-length utterances per GPU, "
                                "5 s prompt, 75 forced speech tokens (3 s) each, LM greedy -> 10-step CFG flow (DiT-22) -> HiFT",
                    "batch_per_gpu": BATCH, "tokens_per_utt": N_TOK, "prompt_tokens": P_TOK, "parallelism": f"dp{world}",
-                   "steps_pipelined": pipelined, "llm_streams": n_llm, "lm_group": group, "flow_workers": a.flow_workers if pipelined else 1,
+                   "steps_pipelined": pipelined, "llm_streams": n_llm, "lm_group": group, "flow_workers": a.flow_workers if pipelined else 1, "flow_group": a.flow_group if pipelined else 1,
                    "lm_rows_per_weight_pass": BATCH * group,
                    "utterances_in_flight_max": BATCH * (3 * group * n_llm + a.flow_workers) if pipelined else BATCH,
                    "in_flight_note": "one LM call decodes lm_group steps' batches together; the ids of up to 2 x lm_group finished batches wait in a queue; flow_workers batches are in the flow decoder / vocoder side by side",

@@ -32,7 +32,8 @@ class CosyVoice3Model:
                  max_batch: int = 8, max_text: int = 128, max_prompt_tokens: int = 800, max_tokens: int = 800,
                  rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
                  sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False, n_llm: int = 1,
-                 sampler: str = "greedy", sampler_seed: int = 1986, lm_group: int = 1, concurrency: int = 1, flow_workers: int = 1):
+                 sampler: str = "greedy", sampler_seed: int = 1986, lm_group: int = 1, concurrency: int = 1, flow_workers: int = 1,
+                 flow_group: int = 1):
         if not torch.cuda.is_available():
             raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -53,8 +54,13 @@ class CosyVoice3Model:
         # step for up to 8 sequences: lowest latency.
         # tts_pipeline switches its LM handles to the per-operation path for its duration (below): a persistent grid needs
         # 152 CUs to itself, which it never has beside the flow stream or on a CU-masked stream.
-        self.flow = FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device)
-        self.hift = HiftEngine(hift_weights, cfg.hift, max_batch=max_batch, max_frames=2 * max_tokens, device=self.device)
+        # flow_group > 1: tts_pipeline hands the flow decoder + vocoder that many consecutive batches in ONE call (their utterances
+        # side by side in one ragged batch): a DiT product over more rows wastes less of its last round of tiles (DESIGN.md
+        # section 10: 9.65 us per sequence and block at 16 sequences, 8.76 at 32)
+        self.flow_group = max(1, flow_group)
+        fb = max_batch * self.flow_group
+        self.flow = FlowEngine(flow_weights, cfg.flow, max_batch=fb, max_frames=max_frames, device=self.device)
+        self.hift = HiftEngine(hift_weights, cfg.hift, max_batch=fb, max_frames=2 * max_tokens, device=self.device)
         # The reference lets several threads enter tts() on one model object (a gRPC pool, runtime/python/grpc/server.py:68-69;
         # per-call state keyed by uuid, cli/model.py:330-333).  An engine handle is single-threaded, so concurrent calls each
         # take a LANE - an own (LM, flow, vocoder) handle set and stream; `concurrency` lanes exist (the reference's
@@ -75,8 +81,8 @@ class CosyVoice3Model:
         # product's time) overlap the other batch's K loops
         self._flow_sets = [_Lane(None, self.flow, self.hift, None)]
         for _ in range(1, max(1, flow_workers)):
-            self._flow_sets.append(_Lane(None, FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device),
-                                         HiftEngine(hift_weights, cfg.hift, max_batch=max_batch, max_frames=2 * max_tokens, device=self.device), None))
+            self._flow_sets.append(_Lane(None, FlowEngine(flow_weights, cfg.flow, max_batch=fb, max_frames=max_frames, device=self.device),
+                                         HiftEngine(hift_weights, cfg.hift, max_batch=fb, max_frames=2 * max_tokens, device=self.device), None))
         # `model.llm.load_state_dict` (compare_inference.py:42 swaps a fine-tuned LM in) must reach every LM handle
         self.llm._peers = [e for e in self.llms[1:]] + [ln.llm for ln in self.lanes[1:]]
         self._count_mu = threading.Lock()
@@ -315,7 +321,7 @@ class CosyVoice3Model:
 
         n_flow = len(self._flow_sets)
         work_q = [queue.Queue() for _ in range(n_flow)]
-        res_q = [queue.Queue(maxsize=2) for _ in range(n_flow)]          # a worker enqueues at most two batches ahead of the consumer
+        res_q = [queue.Queue(maxsize=2 * self.flow_group) for _ in range(n_flow)]
 
         def take(q):
             while not stop.is_set():
@@ -339,17 +345,28 @@ class CosyVoice3Model:
             fs, st = self._flow_sets[w], flow_streams[w]
             try:
                 with torch.cuda.device(dev):
-                    for bi in range(w, len(batches), n_flow):
-                        got = take(work_q[w])
-                        if got is None:
-                            return
-                        _, item, t1 = got
-                        if isinstance(item, BaseException):
-                            res_q[w].put(item)
-                            return
-                        inputs, out, n_tok = item
-                        if min(n_tok) < 1:
-                            raise RuntimeError("the language model emitted no speech token for an utterance")
+                    mine = list(range(w, len(batches), n_flow))
+                    FG = self.flow_group
+                    for g0 in range(0, len(mine), FG):
+                        parts = []
+                        for bi in mine[g0: g0 + FG]:               # this worker's next flow_group batches, one ragged batch
+                            got = take(work_q[w])
+                            if got is None:
+                                return
+                            _, item, t1 = got
+                            if isinstance(item, BaseException):
+                                res_q[w].put(item)
+                                return
+                            if min(item[2]) < 1:
+                                raise RuntimeError("the language model emitted no speech token for an utterance")
+                            parts.append(item)
+                        sizes = [len(p[0]) for p in parts]
+                        inputs = [d for p in parts for d in p[0]]
+                        n_tok = [n for p in parts for n in p[2]]
+                        ld = max(p[1].shape[1] for p in parts)
+                        out = parts[0][1] if len(parts) == 1 else torch.cat(
+                            [torch.nn.functional.pad(p[1], (0, ld - p[1].shape[1])) for p in parts], dim=0)
+                        bi = mine[g0]
                         # The worker waits for its batch before it takes the next one.  Measured against running ahead (the batch's
                         # completion as an event for the consumer's stream, the next batch enqueued behind it at once - possible
                         # since neither engine call synchronises the stream any more: their length tables ride in kernel
@@ -369,8 +386,13 @@ class CosyVoice3Model:
                         if trace:
                             print(f"[pipe] batch {bi} (flow worker {w}): launches enqueued {1e3 * (t2 - t1):.1f} ms after its ids arrived",
                                   file=sys.stderr)
-                        if not put(res_q[w], (res, samples, [out[b, : n_tok[b]] for b in range(len(inputs))], mel, frames, ev)):
-                            return
+                        o = 0
+                        for nb in sizes:                           # handed out batch by batch, in order
+                            r = (res[o: o + nb], samples[o: o + nb], [out[b, : n_tok[b]] for b in range(o, o + nb)], mel[o: o + nb],
+                                 frames[o: o + nb], ev)
+                            if not put(res_q[w], r):
+                                return
+                            o += nb
             except BaseException as e:                            # surfaces in the consumer
                 res_q[w].put(e)
 

@@ -6,7 +6,7 @@ STEPS=${2:-20}
 for cfg in $1; do
   IFS=: read s g x w <<< "$cfg"; w=${w:-1}
   f=$O/r3_sweep_s${s}_g${g}_x${x}.json
-  timeout -k 10 300 python3 $R/bench.py --no-cpu-baseline --no-extras --llm-streams $s --lm-group $g --flow-cu-exclude $x --flow-workers $w --steps $STEPS --warmup 4 > $f 2> $O/r3_sweep.err || { tail -5 $O/r3_sweep.err; exit 1; }
+  timeout -k 10 300 python3 $R/bench.py --no-cpu-baseline --no-extras --llm-streams $s --lm-group $g --flow-cu-exclude $x --flow-workers $w $EXTRA --steps $STEPS --warmup 4 > $f 2> $O/r3_sweep.err || { tail -5 $O/r3_sweep.err; exit 1; }
   python3 - $f $cfg <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

@@ -226,8 +226,8 @@ def test_pipeline_two_lm_handles(tiny):
             assert maxerr(w[b, : s[b]], w2[b, : s2[b]]) < 1e-5
 
 
-@pytest.mark.parametrize("sampler", ["greedy", "ras"])
-def test_pipeline_groups_of_batches_in_one_lm_call(sampler):
+@pytest.mark.parametrize("sampler,flow_group", [("greedy", 1), ("ras", 1), ("greedy", 2)])
+def test_pipeline_groups_of_batches_in_one_lm_call(sampler, flow_group):
     """The benchmark's configuration in miniature: ONE LM call decodes the batches of `lm_group` consecutive steps together (more
     than 8 rows per weight pass: gemv32.hip), two flow workers run side by side - and every batch is what tts_batch returns for it
     (ids identical, waveform <= 1e-5), under the greedy rule and under repetition-aware sampling (a batch's uniforms are seeded by
@@ -237,7 +237,7 @@ def test_pipeline_groups_of_batches_in_one_lm_call(sampler):
     sd = [synth.state_dict_torch(mm.manifest(), DEV, skip=("lm_head",)) for mm in (cfg.llm, cfg.flow, cfg.hift)]
     kw = dict(device=DEV, max_batch=4, max_text=32, max_prompt_tokens=32, max_tokens=160, sampler=sampler, sampler_seed=11)
     a = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, **kw)
-    b = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, lm_group=3, flow_workers=2, **kw)
+    b = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, lm_group=3, flow_workers=2, flow_group=flow_group, **kw)      # flow_group: batches per flow call
     b.rand_noise, b.rand_ini, b.sine_noise = a.rand_noise, a.rand_ini, a.sine_noise
     ins = [e2e_input(cfg, *c)[0] for c in CASES]
     batches = [[ins[0], ins[1], ins[0], ins[1]], [ins[1]], [ins[1], ins[0], ins[0]], [ins[0]], [ins[0], ins[1]], [ins[1], ins[1]], [ins[0]]]
