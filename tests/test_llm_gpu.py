@@ -125,6 +125,23 @@ def test_eight_row_products_equal_the_32_row_products(monkeypatch):
             eng.close()
 
 
+def test_persistent_plan_recreated_after_a_generation():
+    """A decode plan destroyed after a generation and a new one created (hipMalloc recycles small allocations and does not clear
+    them): the new plan's flag array and "go" word are allocated and zeroed by decode_create, so its first launches hand off
+    properly - ids equal the per-operation path's and the fixture's, several times over."""
+    cfg = LlmCfg.tiny()
+    f = golden("llm_tiny.npz")
+    cases = [(12, 8, 0), (10, 6, 30)]
+    for rep in range(4):
+        eng = make(cfg)
+        try:
+            run_cases(_mode(eng, True), f, cases, None, f"tiny.recreated{rep}")
+            if rep == 3:
+                run_cases(_mode(eng, False), f, cases, None, "tiny.recreated.per-op")
+        finally:
+            eng.close()
+
+
 def test_tiny_solo_equals_batched(tiny):
     f = golden("llm_tiny.npz")
     run_cases(tiny, f, [(10, 6, 30)], None, "tiny_solo")
