@@ -17,6 +17,15 @@ Workload (cfg 2 = BASELINE.json configs[1]): instruct text 8 ids + tt
 utterance (3 s of audio each), random-init weights of the CosyVoice3-0.5B architecture
 (fangyan_tts_amd.synth), bf16 MFMA arithmetic for DiT / HiFT, fp32 activations in the LM.
 
+Consecutive steps are software-pipelined (defaults: 40 timed steps, 4 warm-up): ONE speech-token LM call decodes the batches of
+4 consecutive steps together (32 sequences per weight pass, csrc/gemv32.hip) beside the flow decoder + vocoder of the steps
+before; every step still runs the whole path on its own batch of 8 inside the timed region, and the record says what is in flight
+(`config`) and gives the strict one-batch-at-a-time figure beside the headline (`value_batch8_unpipelined`).  `roofline` is the
+kernel family with the largest GPU-time share of the timed region (the DiT linears), measured in the timed configuration with HIP
+events on the launch stream; `roofline_lm` the LM's decode products; every `traffic` comes from `rocprofv3 --pmc` over this very
+program (profiles/r03_bench_pmc.json; tests/micro/prof_r03.sh).  Secondary objects: `precise_mode`, `latency_b1`, `first_chunk`,
+`zero_shot_b4` (configs[2]), `hift_cfg5` (configs[4], output checked), `cpu_baseline`, `checked`.
+
 Prints ONE JSON line (rank 0).
 """
 import argparse
