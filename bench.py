@@ -237,6 +237,26 @@ def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib, steps=3):
                            "launches": n_d, "avg_launch_us": round(1e3 * ms_d / max(n_d, 1), 1)}}
     del m
     torch.cuda.empty_cache()
+    # the same workload through the software pipeline of the headline (one LM call per 4 steps = 16 sequences per weight pass)
+    mp = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=B, max_text=64, max_prompt_tokens=P, max_tokens=N_TOK,
+                         rand_noise=noise, rand_ini=ri, sine_noise=sn, lm_group=4)
+    mp.prepare_pipeline(0)
+    k = 12
+
+    def run_p():
+        for wav_p, samples_p, _ in mp.tts_pipeline([inputs] * k, min_len=[forced] * k, max_len=[forced] * k, keep_on_device=True):
+            wav_p.cpu()
+    run_p()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    run_p()
+    torch.cuda.synchronize()
+    dtp = (time.perf_counter() - t2) / k
+    out["pipelined"] = {"ms_per_step": round(1e3 * dtp, 2), "audio_s_per_s": round(audio / dtp, 2), "steps": k, "lm_group": 4,
+                        "note": "tts_pipeline as in the headline run: the LM of 4 steps' batches in one call beside the flow decoder"}
+    mp.close()
+    del mp
+    torch.cuda.empty_cache()
     return out
 
 
