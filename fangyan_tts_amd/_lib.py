@@ -109,6 +109,9 @@ def _declare(L):
     L.fy_prompt_mel_destroy.restype = None
     L.fy_prompt_mel_frames.argtypes = [i32]
     L.fy_prompt_mel_run.argtypes = [vp, vp, i32, vp, i32, vp]
+    L.fy_allgather_audio_scratch_floats.argtypes = [i32, i32, i32]
+    L.fy_allgather_audio_scratch_floats.restype = C.c_size_t
+    L.fy_allgather_audio.argtypes = [vp, i32, vp, C.c_int64, vp, i32, i32, i32, vp, vp, vp, vp]
     L.fy_synth_uniform.argtypes = [vp, C.c_int64, C.c_uint64, C.c_int64, C.c_double, C.c_double, u32, vp]
     L.fy_audio_feat_create.argtypes = [C.POINTER(vp), i32, vp]
     L.fy_audio_feat_destroy.argtypes = [vp]

@@ -1,0 +1,65 @@
+// The one exchange of the data-parallel path as a C entry (fy_allgather_audio): every rank's finished audio and its
+// lengths to every rank in ONE fused, fixed-size all-gather over RCCL (xGMI inside a node).  The reference's multi-GPU inference
+// gathers nothing - each rank writes its own files (CosyVoice/runtime/triton_trtllm/offline_inference.py:312-322); north_star
+// asks for the all-gather of the finished audio.  Python hosts use fangyan_tts_amd/parallel.py:gather_audio over
+// torch.distributed (the process group is theirs); this entry is for a host that owns an RCCL communicator itself.
+//
+// The library does NOT link RCCL: a process must hold ONE copy of it (and of the HIP runtime under it), and which copy is the
+// host's choice (torch bundles its own).  The entry resolves ncclAllGather from whatever RCCL the process has loaded with global
+// symbol visibility (dlsym(RTLD_DEFAULT)); without one it fails with FY_ERR_STATE and says so.
+#include "runtime.h"
+#include <algorithm>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+// record of one rank: b_max rows of s_max samples, then b_max + 1 int32 (count, lengths) bit-cast to float
+__global__ void ag_pack_k(const float* __restrict__ wav, long wav_ld, const int* __restrict__ n_samples, int b, int b_max, int s_max,
+                          float* __restrict__ rec) {
+    const long n = (long)b_max * s_max;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / s_max), c = (int)(i % s_max);
+        rec[i] = (r < b && c < n_samples[r]) ? wav[(long)r * wav_ld + c] : 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x <= b_max) {
+        const int v = threadIdx.x == 0 ? b : (threadIdx.x - 1 < b ? n_samples[threadIdx.x - 1] : 0);
+        rec[n + threadIdx.x] = __int_as_float(v);
+    }
+}
+// [world][rec] -> wav_all (world * b_max, s_max) and n_all (world, b_max + 1) = count, lengths per rank
+__global__ void ag_unpack_k(const float* __restrict__ recs, int world, int b_max, int s_max, float* __restrict__ wav_all, int* __restrict__ n_all) {
+    const long per = (long)b_max * s_max, rec = per + b_max + 1, n = (long)world * per;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / per;
+        wav_all[i] = recs[r * rec + (i - r * per)];
+    }
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < (long)world * (b_max + 1); i += (long)gridDim.x * 256) {
+        const long r = i / (b_max + 1);
+        n_all[i] = __float_as_int(recs[r * rec + per + (i - r * (b_max + 1))]);
+    }
+}
+
+extern "C" size_t fy_allgather_audio_scratch_floats(int32_t world, int32_t b_max, int32_t s_max) {
+    return (size_t)(world + 1) * ((size_t)b_max * s_max + b_max + 1);
+}
+
+extern "C" int fy_allgather_audio(void* rccl_comm, int32_t world, const float* wav, int64_t wav_ld, const int32_t* n_samples, int32_t b,
+                                  int32_t b_max, int32_t s_max, float* scratch, float* wav_all, int32_t* n_all, void* stream) {
+    FY_CHECK(rccl_comm && wav && n_samples && scratch && wav_all && n_all && world >= 1 && b >= 0 && b <= b_max && b_max >= 1 && b_max <= 255 &&
+                 s_max >= 1 && wav_ld >= 1, FY_ERR_ARG, "fy_allgather_audio: bad arguments (b %d, b_max %d <= 255, s_max %d)", b, b_max, s_max);
+    typedef decltype(&ncclAllGather) allgather_t;
+    static allgather_t ag = (allgather_t)dlsym(RTLD_DEFAULT, "ncclAllGather");
+    FY_CHECK(ag != nullptr, FY_ERR_STATE, "fy_allgather_audio: no RCCL in this process (ncclAllGather not found: load librccl.so with global symbol "
+             "visibility - the copy the communicator was made with - before the call)");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t rec = (size_t)b_max * s_max + b_max + 1;
+    float* mine = scratch;                                   // [rec]
+    float* all = scratch + rec;                              // [world][rec]
+    const long n = (long)b_max * s_max;
+    hipLaunchKernelGGL(ag_pack_k, dim3((unsigned)std::min<long>(4096, (n + 255) / 256)), dim3(256), 0, st, wav, (long)wav_ld, n_samples, b, b_max, s_max, mine);
+    HIP_TRY(hipGetLastError());
+    const ncclResult_t rc = ag(mine, all, rec, ncclFloat, (ncclComm_t)rccl_comm, st);
+    FY_CHECK(rc == ncclSuccess, FY_ERR_HIP, "fy_allgather_audio: ncclAllGather failed (%d)", (int)rc);
+    hipLaunchKernelGGL(ag_unpack_k, dim3((unsigned)std::min<long>(4096, ((long)world * n + 255) / 256)), dim3(256), 0, st, all, world, b_max, s_max, wav_all, n_all);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}

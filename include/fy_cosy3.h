@@ -15,6 +15,7 @@
  */
 #ifndef FY_COSY3_H
 #define FY_COSY3_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -230,6 +231,17 @@ void fy_audio_feat_destroy(fy_audio_feat* p);
 int fy_audio_feat_mels(const fy_audio_feat* p);
 int fy_audio_feat_frames(const fy_audio_feat* p, int64_t n_samples);
 int fy_audio_feat_run(fy_audio_feat* p, const float* wav, int64_t n_samples, float* out, int32_t frames, uint32_t flags, void* stream);
+
+/* ================================ multi-GPU: the all-gather of the finished audio ================================
+ * north_star's one exchange: every rank's b <= b_max finished utterances (wav (b, wav_ld) fp32 on the device, valid
+ * lengths n_samples (b) int32 on the device) to every rank in ONE fixed-size ncclAllGather on `stream`:
+ * wav_all (world * b_max, s_max) in rank order, zero-padded; n_all (world, b_max + 1) int32 = count, lengths of each rank.
+ * rccl_comm: the caller's ncclComm_t.  The library does not link RCCL - it calls the copy the process already holds (loaded with
+ * global symbol visibility); FY_ERR_STATE when there is none.  scratch: fy_allgather_audio_scratch_floats(world, b_max, s_max)
+ * floats on the device.  Python hosts use fangyan_tts_amd.parallel.gather_audio over torch.distributed instead.              */
+size_t fy_allgather_audio_scratch_floats(int32_t world, int32_t b_max, int32_t s_max);
+int fy_allgather_audio(void* rccl_comm, int32_t world, const float* wav, int64_t wav_ld, const int32_t* n_samples, int32_t b,
+                       int32_t b_max, int32_t s_max, float* scratch, float* wav_all, int32_t* n_all, void* stream);
 
 /* ================================ tooling: synthetic tensors ================================
  * No pretrained checkpoint is reachable offline: tests and bench.py fill the model from a counter-based generator

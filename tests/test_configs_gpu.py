@@ -216,3 +216,59 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     # 2 ranks x 8 utterances x 3 s per step
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 8 * 3.0) < 1e-3
+
+
+def test_allgather_audio_c_entry_single_rank(tmp_path):
+    """fy_allgather_audio (the C entry a host with its own RCCL communicator calls; Python hosts use parallel.gather_audio) on a
+    one-rank communicator made with the RCCL copy torch ships: the fixed-size record is packed, gathered and unpacked - audio
+    zero-padded to (b_max, s_max), count and lengths behind it.  In a child process with a time limit: a communicator cannot be
+    made on every box (no usable network interface for the bootstrap), which skips the test instead of hanging the suite."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import ctypes as C, os, sys, torch
+torch.cuda.set_device(0)
+from fangyan_tts_amd import _lib
+L = _lib.lib()
+assert L.fy_allgather_audio(None, 1, None, 1, None, 0, 1, 1, None, None, None, None) != 0          # argument check, no RCCL needed
+rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+class UID(C.Structure):
+    _fields_ = [("b", C.c_char * 128)]
+uid = UID()
+if rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+    print("SKIP ncclGetUniqueId"); sys.exit(0)
+comm = C.c_void_p()
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+if rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) != 0:
+    print("SKIP ncclCommInitRank"); sys.exit(0)
+dev = torch.device("cuda:0")
+b, b_max, s_max, ld = 3, 4, 1000, 1200
+g = torch.Generator().manual_seed(1)
+wav = torch.rand(b, ld, generator=g).to(dev)
+lens = torch.tensor([1000, 17, 640], dtype=torch.int32, device=dev)
+scratch = torch.zeros(L.fy_allgather_audio_scratch_floats(1, b_max, s_max), device=dev)
+wav_all = torch.full((b_max, s_max), -7.0, device=dev)
+n_all = torch.full((1, b_max + 1), -1, dtype=torch.int32, device=dev)
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_lib.check(L.fy_allgather_audio(comm, 1, wav.data_ptr(), ld, lens.data_ptr(), b, b_max, s_max, scratch.data_ptr(), wav_all.data_ptr(), n_all.data_ptr(), st))
+torch.cuda.synchronize()
+assert n_all.cpu().tolist() == [[3, 1000, 17, 640, 0]], n_all
+for r, n in enumerate([1000, 17, 640]):
+    assert torch.equal(wav_all[r, :n], wav[r, :n]) and float(wav_all[r, n:].abs().max() if n < s_max else 0.0) == 0.0
+assert float(wav_all[3].abs().max()) == 0.0
+rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+rccl.ncclCommDestroy(comm)
+print("OK")
+"""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root] + sys.path), NCCL_SOCKET_IFNAME=os.environ.get("NCCL_SOCKET_IFNAME", "lo"),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    try:
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=180)
+    except subprocess.TimeoutExpired:
+        pytest.skip("making a one-rank RCCL communicator did not finish on this box")
+    assert r.returncode == 0, r.stderr[-2000:]
+    if "SKIP" in r.stdout:
+        pytest.skip(r.stdout.strip())
+    assert "OK" in r.stdout
