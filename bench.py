@@ -182,37 +182,22 @@ def dit_roofline(ms, flops, n, where, traffic):
             "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2), "gflop_per_launch": round(flops / max(n, 1) / 1e9, 3), "measured_over": where}
 
 
-def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib, steps=3):
-    """BASELINE.json configs[2] as a secondary object: zero-shot with a 10 s prompt (30 prompt-text ids, 250 prompt speech
-    tokens in the LM = a ~296-row prefill per sequence, 500 prompt mel frames: DiT sequence 650), batch 4, 75 forced tokens,
-    steps one after the other on one stream."""
+def zero_shot_inputs(cfg, B=4, P=250):
+    """configs[2]'s synthetic batch: 14 text ids behind 30 prompt-text ids, P prompt speech tokens (LM and flow), 2 P prompt mel frames."""
     import numpy as np
     from fangyan_tts_amd import synth
-    from fangyan_tts_amd.cli.model import CosyVoice3Model
-    B, P = 4, 250
-    noise = torch.from_numpy(synth.flow_rand_noise(2 * (P + N_TOK))).to(dev)
-    ri = torch.from_numpy(synth.hift_rand_ini()).to(dev)
-    sn = torch.from_numpy(synth.hift_sine_noise(2 * N_TOK * 480)).to(dev)
-    m = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=B, max_text=64, max_prompt_tokens=P, max_tokens=N_TOK,
-                        rand_noise=noise, rand_ini=ri, sine_noise=sn)
-    hi = min(cfg.llm.vocab, 151643)
-    inputs = []
-    for b in range(B):
-        tag = f"bench.zs.u{b}"
-        ptok = torch.from_numpy(synth.randint(tag + ".ptok", (1, P), 0, cfg.flow.vocab))
-        inputs.append({"text": torch.from_numpy(synth.randint(tag + ".text", (1, 14), 0, hi)),
-                       "prompt_text": torch.from_numpy(synth.randint(tag + ".ptext", (1, 30), 0, hi)),
-                       "llm_prompt_speech_token": ptok, "flow_prompt_speech_token": ptok,
-                       "prompt_speech_feat": torch.from_numpy(np.clip(synth.normal(tag + ".pfeat", (1, 2 * P, 80), -5.0, 2.0), -11.5, 2.0)),
-                       "flow_embedding": torch.from_numpy(synth.normal(tag + ".spk", (1, 192)))})
+    inputs = zero_shot_inputs(cfg, B, P)
     forced = [N_TOK] * B
     m.tts_batch(inputs, min_len=forced, max_len=forced)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        wav, samples, _ = m.tts_batch(inputs, min_len=forced, max_len=forced)          # wavs end on the host
+        wav, samples, toks = m.tts_batch(inputs, min_len=forced, max_len=forced)          # wavs end on the host
     dt = (time.perf_counter() - t0) / steps
     audio = sum(samples) / 24000.0
+    # utterances 0 and 3 of the last timed step, for the check against the CPU oracle (check_zero_shot, in the cpu_baseline leg)
+    keep = {"inputs": inputs, "noise": noise, "ri": ri, "sn": sn, "samples": samples, "wav": wav.clone(),
+            "toks": [t.cpu() for t in toks], "mel": m.last_mel.float().cpu()}
     # where the time goes: the LM alone (prefill of 4 x 296 rows + 75 token steps), then every profiled stage of one step
     text = [d["text"].reshape(-1).tolist() for d in inputs]
     ptext = [d["prompt_text"].reshape(-1).tolist() for d in inputs]
@@ -257,7 +242,35 @@ def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib, steps=3):
     mp.close()
     del mp
     torch.cuda.empty_cache()
-    return out
+    return out, keep
+
+
+def check_zero_shot(cfg, sd_llm, sd_flow, sd_hift, keep, which=(0, 3)):
+    """BASELINE.json configs[2] at full size: utterances 0 and 3 of the timed batch-4 step (10 s prompt: 296-row LM prefill, DiT
+    sequence 650 = M 5200 for the batch) against the CPU oracle's whole per-utterance path - ids exact, mel <= 4e-2, waveform
+    <= 2.5e-3 from the oracle vocoder on the engine's own mel (the same bars as the headline's `checked`)."""
+    from oracle import hift as ohift, pipeline as opipe
+    PL = {k: v.cpu() for k, v in sd_llm.items()}
+    PF = {k: v.cpu() for k, v in sd_flow.items()}
+    PH = ohift.prepare({k: v.cpu().numpy() for k, v in sd_hift.items()})
+    noise, ri, sn = keep["noise"].cpu(), keep["ri"].cpu(), keep["sn"].cpu()
+    res, ok = [], True
+    t0 = time.time()
+    for b in which:
+        ref = opipe.tts(keep["inputs"][b], PL, PF, PH, cfg, noise, ri, sn, min_len=N_TOK, max_len=N_TOK)
+        ids, ref_ids = keep["toks"][b].reshape(-1).tolist(), ref["tokens"].reshape(-1).tolist()
+        n = len(ref_ids)
+        mel = keep["mel"][b: b + 1, :, : 2 * n]
+        e_mel = float((mel - ref["mel"]).abs().max()) if mel.shape == ref["mel"].shape else float("inf")
+        S = keep["samples"][b]
+        ref_wav, _ = ohift.inference(mel, PH, cfg.hift, ri, sn[:, :S])
+        e_wav = float((keep["wav"][b: b + 1, :S] - ref_wav).abs().max())
+        good = bool(ids == ref_ids and e_mel <= 4e-2 and e_wav <= 2.5e-3)
+        ok &= good
+        res.append({"utterance": b, "ids_equal": ids == ref_ids, "n_ids": n, "mel_max_abs_err": round(e_mel, 5),
+                    "wav_vs_oracle_vocoder_on_engine_mel": round(e_wav, 6), "ok": good})
+    return {"what": "utterances 0 and 3 of the last timed full-size batch-4 step vs the CPU oracle (oracle.pipeline.tts)", "mel_tol": 4e-2, "wav_tol": 2.5e-3,
+            "utterances": res, "oracle_s": round(time.time() - t0, 1), "ok": bool(ok)}
 
 
 def bench_latency_b1(cfg, sd_llm, sd_flow, sd_hift, dev, inputs, reps=4):
@@ -408,14 +421,20 @@ def main():
     def step():
         return deliver(*model.tts_batch(inputs, min_len=forced, max_len=forced, keep_on_device=True))
 
-    def run(k):
+    def fresh(ins):
+        """The same utterances as NEW tensor objects: what a host that builds its model_input dicts per request presents (the
+        prompt cache of cli/model.py is keyed by tensor identity, so every step pads and copies its prompts to the device)."""
+        return [{k: v.clone() for k, v in d.items()} for d in ins]
+
+    def run(k, fresh_inputs=False):
         """k steps.  Consecutive steps are software-pipelined over HIP streams: the speech-token LM decodes the batches of
         `lm_group` consecutive steps in ONE call (32 sequences per weight pass) beside the flow decoder + vocoder of the
         steps before; every step still runs the whole path on its own batch of 8, inside the timed region."""
         if not pipelined:
             return [step() for _ in range(k)][-1]
         samples = None
-        for out in model.tts_pipeline([inputs] * k, min_len=[forced] * k, max_len=[forced] * k, keep_on_device=True,
+        steps_in = [fresh(inputs) for _ in range(k)] if fresh_inputs else [inputs] * k
+        for out in model.tts_pipeline(steps_in, min_len=[forced] * k, max_len=[forced] * k, keep_on_device=True,
                                       flow_cu_exclude=a.flow_cu_exclude, lm_isolate=a.lm_isolate):
             samples = deliver(*out)
         return samples
@@ -428,12 +447,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    cpu0 = time.process_time()                      # CPU seconds of this process, every thread (LM producer, feeder, flow workers, consumer)
     t0 = time.perf_counter()
     samples = run(a.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    host_cpu_ms = 1e3 * (time.process_time() - cpu0) / a.steps
     timed = {k: (v.clone() if torch.is_tensor(v) else [t.cpu() for t in v]) for k, v in last.items()}      # the last timed step's outputs
     if world > 1:
         t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
@@ -442,6 +463,24 @@ def main():
     audio_per_step = world * sum(samples) / 24000.0
     value = audio_per_step * a.steps / dt
     log(f"timed {a.steps} steps: {1e3 * dt / a.steps:.1f} ms/step, {value:.1f} audio_s/s")
+
+    # ---- the same K steps with FRESH input tensors per step (SURVEY 8d starts the clock at "model_input dicts resident on host"): the
+    # prompt cache never hits, every step pads its prompts and copies them to the device (3 H2D copies + a stream wait per batch)
+    value_fresh = None
+    if pipelined:
+        torch.cuda.synchronize()
+        tf = time.perf_counter()
+        run(a.steps, fresh_inputs=True)
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - tf
+        if world > 1:
+            t = torch.tensor([dtf], device="cpu" if rehearsal else dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtf = float(t.item())
+        value_fresh = {"value": round(audio_per_step * a.steps / dtf, 3), "ms_per_step": round(1e3 * dtf / a.steps, 3),
+                       "note": "the timed run repeated with new tensor objects for every step's model_input dicts: the prompt cache (keyed by tensor identity) "
+                               "never hits, so prompt padding + 3 host-to-device copies + a stream wait per batch are inside the step"}
+        log(f"fresh inputs: {1e3 * dtf / a.steps:.1f} ms/step")
 
     # ---- roofline of the timed configuration: the SAME K steps twice more, with HIP events (on the stream each kernel is
     # launched on) around every launch of one kernel family per pass - the DiT linears on the flow stream, then the LM's
@@ -538,6 +577,7 @@ def main():
     # ---- the price of the reference's own estimator-swap bar (rtol 1e-2 / atol 1e-4, export_onnx.py:109): the flow decoder in its
     # fp32-class mode (FY_PRECISE: split operands, fp32 attention), un-pipelined steps
     precise = None
+    zs_keep = None
     if rank == 0 and world == 1 and not a.no_extras:
         model.flow_flags = _lib.FY_PRECISE
         try:
@@ -569,6 +609,10 @@ def main():
                    "weights": "random-init, CosyVoice3-0.5B shapes (859 M params)"},
         # the strict batch-8 figure: one batch at a time, nothing of another batch in flight (tts_batch; LM on the persistent step)
         "value_batch8_unpipelined": round(audio_per_step / (latency_ms * 1e-3), 2),
+        "value_fresh_inputs": value_fresh,
+        # CPU time this rank's process spent per timed step, all threads (time.process_time over the timed region): what 8 ranks on
+        # one host need of it (x 8) against the host's cores
+        "host_cpu_ms_per_step": round(host_cpu_ms, 2),
         "roofline": roofline,
         "roofline_lm": roofline_lm,
         "roofline_lm_persistent": roofline_lm_p,
@@ -581,7 +625,7 @@ def main():
         log("first streaming chunk")
         out["first_chunk"] = bench_first_chunk(cfg, sd_llm, sd_flow, sd_hift, dev, inputs)
         log("zero-shot batch 4 (config 3)")
-        out["zero_shot_b4"] = bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib)
+        out["zero_shot_b4"], zs_keep = bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib)
         log("HiFT-only 32 x 10 000 frames (config 5)")
         model.close()
         del model, eng
@@ -593,6 +637,9 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log("timing the CPU oracle on one utterance")
         out["cpu_baseline"], out["checked"] = cpu_baseline(cfg, sd_llm, sd_flow, sd_hift, inputs[0], noise, ri, sn, timed)
+        if zs_keep is not None:
+            log("checking the zero-shot batch against the CPU oracle")
+            out["zero_shot_b4"]["checked"] = check_zero_shot(cfg, sd_llm, sd_flow, sd_hift, zs_keep)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

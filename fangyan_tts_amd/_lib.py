@@ -102,6 +102,7 @@ def _declare(L):
     L.fy_stream_overlap.argtypes = [C.POINTER(C.c_void_p), i32, vp]
     L.fy_mel_speed.argtypes = [vp, i32, i32, vp, i32, vp]
     L.fy_llm_begin.argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, i32, vp, i32, vp]
+    L.fy_llm_prefill.argtypes = [vp, vp, i32, i32p, i32p, i32p, i32, vp, i32, vp]
     L.fy_llm_step.argtypes = [vp, i32, vp, i32, vp, vp, i32p, vp]
     L.fy_llm_logp.argtypes = [vp, i32, f32p, vp]
     L.fy_prompt_mel_create.argtypes = [C.POINTER(vp), i32, vp]
@@ -112,6 +113,7 @@ def _declare(L):
     L.fy_allgather_audio_scratch_floats.argtypes = [i32, i32, i32]
     L.fy_allgather_audio_scratch_floats.restype = C.c_size_t
     L.fy_allgather_audio.argtypes = [vp, i32, vp, C.c_int64, vp, i32, i32, i32, vp, vp, vp, vp]
+    L.fy_audio_record_pack.argtypes = [vp, C.c_int64, i32p, i32, i32, i32, vp, vp]
     L.fy_synth_uniform.argtypes = [vp, C.c_int64, C.c_uint64, C.c_int64, C.c_double, C.c_double, u32, vp]
     L.fy_audio_feat_create.argtypes = [C.POINTER(vp), i32, vp]
     L.fy_audio_feat_destroy.argtypes = [vp]

@@ -11,12 +11,20 @@ What the reference's frontend is made of, and what stands here:
     (tokenizer/tokenizer.py:274-313)                    <model_dir>/CosyVoice-BlankEN + the token table) - or inject one
   prompt mel: matcha mel_spectrogram                    `PromptMel`: HIP kernel (csrc/frontend.hip) through the C ABI
     (matcha/utils/audio.py:45-82)
-  speech tokens: whisper log-mel -> ORT                 injected callable `speech_tokenizer(wav16k) -> list[int]`
-    speech_tokenizer_v3.onnx (frontend.py:94-108)       (onnxruntime / whisper are not in this image)
-  x-vector: kaldi fbank -> ORT campplus.onnx            injected callable `spk_embedder(wav16k) -> (1, 192)`
-    (frontend.py:110-117)
-  load_wav: torchaudio load + Resample                  `load_wav`: scipy wav reader + polyphase resampling (NOT
-    (utils/file_utils.py:44-50)                         torchaudio's kernel: parity unpinned, torchaudio is absent)
+  speech tokens: whisper log-mel -> ORT                 `AudioFeat("whisper")`: whisper's 128-bin log-mel as a HIP kernel
+    speech_tokenizer_v3.onnx (frontend.py:94-108)       (csrc/frontend_feats.hip, fy_audio_feat_*), fed to the ONNX session
+                                                        `onnx_prompt_models(model_dir)` builds when onnxruntime imports and
+                                                        the .onnx files are there; else an injected callable
+                                                        `speech_tokenizer(wav16k) -> list[int]`.  onnxruntime is NOT in this
+                                                        image: the session branch has never executed here (the algorithm of
+                                                        whisper's log-mel is restated: parity unpinned, whisper is absent)
+  x-vector: kaldi fbank -> ORT campplus.onnx            `AudioFeat("fbank")`: kaldi's 80-bin fbank minus its mean, same
+    (frontend.py:110-117)                               kernel file, same session rule; else an injected callable
+                                                        `spk_embedder(wav16k) -> (1, 192)` (torchaudio absent: unpinned)
+  load_wav: torchaudio load + Resample                  `load_wav`: scipy wav reader + `resample`, torchaudio's default
+    (utils/file_utils.py:44-50)                         windowed-sinc filter bank (Hann, width 6, rolloff 0.99) restated and
+                                                        held to a sample-by-sample evaluation of the published formula
+                                                        (parity with torchaudio itself unpinned: it is absent)
   number spelling (inflect), wetext / ttsfrd            injected `number_speller` / `text_normalizer`; absent = the
                                                         reference's own no-frontend fallback (frontend.py:73-75)
 

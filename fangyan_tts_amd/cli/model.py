@@ -33,11 +33,17 @@ class CosyVoice3Model:
                  rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
                  sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False, n_llm: int = 1,
                  sampler: str = "greedy", sampler_seed: int = 1986, lm_group: int = 1, concurrency: int = 1, flow_workers: int = 1,
-                 flow_group: int = 1):
+                 flow_group: int = 1, cache_prompts: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.cfg, self.fp16 = cfg, fp16
+        # cache_prompts: keep the padded device copies of the prompts a call presented (tokens, mel, x-vector), keyed by the
+        # identity and in-place version counter of the caller's tensors - a serving loop presents the same prompts again and
+        # again.  The key cannot see a tensor rewritten behind torch's back (`.data` assignment, memory shared with numpy, a
+        # kernel writing through data_ptr()): callers that do that, or that never repeat a prompt, pass False - every call then
+        # pads and copies its prompts afresh.
+        self.cache_prompts = bool(cache_prompts)
         self.max_batch, self.max_tokens, self.max_prompt_tokens = max_batch, max_tokens, max_prompt_tokens
         max_frames = 2 * (max_tokens + max_prompt_tokens)
         # n_llm > 1: extra LM handles (own KV cache and workspace) so tts_pipeline can decode several batches at once;
@@ -413,7 +419,11 @@ class CosyVoice3Model:
                             r = res_q[bi % n_flow].get(timeout=0.5)
                         except queue.Empty:
                             if not any(t.is_alive() for t in threads[n_prod + 1:]):
-                                raise RuntimeError("tts_pipeline: the flow workers ended without a result")
+                                # a worker may have put its last result and ended between the time-out and the liveness test
+                                try:
+                                    r = res_q[bi % n_flow].get_nowait()
+                                except queue.Empty:
+                                    raise RuntimeError("tts_pipeline: the flow workers ended without a result")
                     if isinstance(r, BaseException):
                         raise r
                     res, samples, toks, mel, frames, ev = r
@@ -531,7 +541,7 @@ class CosyVoice3Model:
         tensors' identities and in-place version counters; the cache keeps the tensors alive)."""
         cache = self.__dict__.setdefault("_prompt_cache", {})
         key = tuple((id(t), t._version) for d in inputs for t in (d["flow_prompt_speech_token"], d["prompt_speech_feat"], d["flow_embedding"]))
-        hit = cache.get(key)
+        hit = cache.get(key) if self.cache_prompts else None
         if hit is not None:
             return hit[1]
         B = len(inputs)
@@ -546,6 +556,8 @@ class CosyVoice3Model:
         emb = torch.cat([d["flow_embedding"].reshape(1, -1) for d in inputs]).float()
         val = (ptok.to(self.device), [len(t) for t in fp], pfeat.to(self.device), [f.shape[0] for f in pf], emb.to(self.device))
         torch.cuda.current_stream(self.device).synchronize()     # the copies are complete before another stream may use them
+        if not self.cache_prompts:
+            return val
         with self._count_mu:                                      # tts_pipeline's flow workers share the cache
             if len(cache) >= 16:
                 cache.pop(next(iter(cache)), None)

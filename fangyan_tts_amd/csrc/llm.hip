@@ -734,6 +734,38 @@ static int llm_sample(fy_llm* l, int B, int32_t* out_ids, int out_ld, int keep_s
     return FY_OK;
 }
 
+// Common tail of fy_llm_begin / fy_llm_prefill: per-sequence state, the prefill over the R packed rows already standing in l->h
+// (fp32, sequence after sequence, n_rows[b] each), the first token.
+static int llm_begin_rows(fy_llm* l, const int* n_rows, const int32_t* min_len, const int32_t* max_len, int B, int32_t* out_ids, int out_ld, hipStream_t st) {
+    const fy_llm_config& c = l->cfg;
+    const int mb = l->max_batch, H = c.hidden;
+    std::vector<int> rseq, rpos, last(mb, 0), stv(8 * mb, 0);
+    int steps = 0;
+    for (int b = 0; b < B; ++b) {
+        const int Lb = n_rows[b];
+        for (int p = 0; p < Lb; ++p) { rseq.push_back(b); rpos.push_back(p); }
+        last[b] = (int)rseq.size() - 1;
+        stv[0 * mb + b] = Lb - 1;          // position of the last prefill token; sample_k advances it
+        stv[5 * mb + b] = min_len[b];
+        stv[6 * mb + b] = max_len[b];
+        steps = std::max(steps, (int)max_len[b]);
+    }
+    for (int b = B; b < mb; ++b) stv[3 * mb + b] = 1;
+    const int R = (int)rseq.size();
+    HIP_TRY(hipMemcpyAsync(l->row_seq, rseq.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(l->row_pos, rpos.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(l->last_row, last.data(), mb * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(l->st, stv.data(), stv.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    l->B = B;
+    if (l->gv32 && !llm_prefill_by_gemm(l, R)) FY_TRY(gv32_split_rows(l->h, H, R, H, l->L[0].ln1, l->img_h, l->ssq, st));
+    FY_TRY(llm_layers(l, R, l->row_seq, l->row_pos, false, st));
+    hipLaunchKernelGGL(gather_rows_k, dim3(B), dim3(256), 0, st, l->h, l->last_row, l->hb, H);
+    FY_TRY(llm_head_and_sample(l, B, l->hb, out_ids, out_ld, 0, st));
+    l->step_next = 1; l->steps_cap = steps;
+    return FY_OK;
+}
+
 extern "C" int fy_llm_begin(fy_llm* l, const int32_t* text_ids, const int32_t* n_text_all, const int32_t* prompt_speech,
                             const int32_t* n_prompt_speech, const int32_t* min_len, const int32_t* max_len, int32_t B,
                             int32_t* out_ids, int32_t out_ld, void* stream) {
@@ -743,10 +775,10 @@ extern "C" int fy_llm_begin(fy_llm* l, const int32_t* text_ids, const int32_t* n
     l->all_done = false;
     FY_CHECK(B >= 1 && B <= l->max_batch && out_ld >= 1, FY_ERR_ARG, "fy_llm_generate: batch %d outside [1, %d]", B, l->max_batch);
     const fy_llm_config& c = l->cfg;
-    const int mb = l->max_batch, H = c.hidden;
+    const int H = c.hidden;
     // lm_input = [sos, embed(prompt_text + text), task_id, speech_embedding(prompt_speech)], llm.py:732-740
-    std::vector<int> src, rseq, rpos, last(mb, 0), stv(8 * mb, 0);
-    int to = 0, po = 0, steps = 0;
+    std::vector<int> src, rows(B, 0);
+    int to = 0, po = 0;
     for (int b = 0; b < B; ++b) {
         const int nt = n_text_all[b], np = n_prompt_speech[b], Lb = 2 + nt + np;
         FY_CHECK(nt >= 1 && np >= 0 && min_len[b] >= 0 && max_len[b] >= 1, FY_ERR_ARG, "fy_llm_generate: sequence %d has bad lengths", b);
@@ -766,33 +798,44 @@ extern "C" int fy_llm_begin(fy_llm* l, const int32_t* text_ids, const int32_t* n
                 FY_CHECK(id >= 0 && id < l->n_speech(), FY_ERR_ARG, "fy_llm_generate: prompt speech id %d out of range", id);
                 s = id | (1 << 30);
             }
-            src.push_back(s); rseq.push_back(b); rpos.push_back(p);
+            src.push_back(s);
         }
-        last[b] = (int)src.size() - 1;
-        stv[0 * mb + b] = Lb - 1;          // position of the last prefill token; sample_k advances it
-        stv[5 * mb + b] = min_len[b];
-        stv[6 * mb + b] = max_len[b];
+        rows[b] = Lb;
         to += nt; po += np;
-        steps = std::max(steps, (int)max_len[b]);
     }
-    for (int b = B; b < mb; ++b) stv[3 * mb + b] = 1;
     const int R = (int)src.size();
     FY_CHECK(R <= l->max_rows, FY_ERR_ARG, "fy_llm_generate: %d prefill rows exceed the workspace (%d)", R, l->max_rows);
     HIP_TRY(hipMemcpyAsync(l->row_src, src.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(l->row_seq, rseq.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(l->row_pos, rpos.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(l->last_row, last.data(), mb * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(l->st, stv.data(), stv.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    l->B = B;
-    // prefill
+    HIP_TRY(hipStreamSynchronize(st));                        // src dies with this frame
     hipLaunchKernelGGL(embed_rows_k, dim3(R), dim3(256), 0, st, l->row_src, l->embed_tokens, l->speech_emb, l->h, H);
-    if (l->gv32 && !llm_prefill_by_gemm(l, R)) FY_TRY(gv32_split_rows(l->h, H, R, H, l->L[0].ln1, l->img_h, l->ssq, st));
-    FY_TRY(llm_layers(l, R, l->row_seq, l->row_pos, false, st));
-    hipLaunchKernelGGL(gather_rows_k, dim3(B), dim3(256), 0, st, l->h, l->last_row, l->hb, H);
-    FY_TRY(llm_head_and_sample(l, B, l->hb, out_ids, out_ld, 0, st));
-    l->step_next = 1; l->steps_cap = steps;
-    return FY_OK;
+    return llm_begin_rows(l, rows.data(), min_len, max_len, B, out_ids, out_ld, st);
+}
+
+// The embeddings-level entry (the reference's vLLM hand-off, llm.py:482-510: the host assembles lm_input itself and
+// passes `prompt_embeds`).  embeds: the B sequences' rows packed back to back, (sum n_rows, hidden), fp32 (dtype 0) or bf16 (1).
+__global__ void rows_from_bf16_k(const bf16_t* __restrict__ src, float* __restrict__ dst, long n) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = bf16_to_f32(src[i]);
+}
+extern "C" int fy_llm_prefill(fy_llm* l, const void* embeds, int32_t dtype, const int32_t* n_rows, const int32_t* min_len, const int32_t* max_len,
+                              int32_t B, int32_t* out_ids, int32_t out_ld, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    FY_CHECK(l && embeds && n_rows && min_len && max_len && out_ids && (dtype == 0 || dtype == 1), FY_ERR_ARG, "fy_llm_prefill: bad argument (dtype 0 = fp32, 1 = bf16)");
+    l->step_next = l->steps_cap = 0;
+    l->all_done = false;
+    FY_CHECK(B >= 1 && B <= l->max_batch && out_ld >= 1, FY_ERR_ARG, "fy_llm_prefill: batch %d outside [1, %d]", B, l->max_batch);
+    const int H = l->cfg.hidden;
+    long R = 0;
+    for (int b = 0; b < B; ++b) {
+        FY_CHECK(n_rows[b] >= 1 && min_len[b] >= 0 && max_len[b] >= 1, FY_ERR_ARG, "fy_llm_prefill: sequence %d has bad lengths", b);
+        FY_CHECK(n_rows[b] + max_len[b] <= l->max_ctx, FY_ERR_ARG, "fy_llm_prefill: sequence %d needs %d positions, the handle has %d", b,
+                 n_rows[b] + max_len[b], l->max_ctx);
+        R += n_rows[b];
+    }
+    FY_CHECK(R <= l->max_rows, FY_ERR_ARG, "fy_llm_prefill: %ld prefill rows exceed the workspace (%d)", R, l->max_rows);
+    if (dtype == 0) HIP_TRY(hipMemcpyAsync(l->h, embeds, (size_t)R * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+    else hipLaunchKernelGGL(rows_from_bf16_k, dim3((unsigned)std::min<long>(2048, (R * H + 255) / 256)), dim3(256), 0, st, (const bf16_t*)embeds, l->h, R * H);
+    HIP_TRY(hipGetLastError());
+    return llm_begin_rows(l, n_rows, min_len, max_len, B, out_ids, out_ld, st);
 }
 
 // decode: row b = sequence b at position st[pos][b]; everything a step needs is on the device

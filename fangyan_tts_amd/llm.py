@@ -111,6 +111,23 @@ class LlmEngine:
         self._gen = (out, out_n, raw_n, len(text))
         return out, out_n, raw_n
 
+    def prefill_embeds(self, embeds: Sequence[torch.Tensor], min_len: Sequence[int], max_len: Sequence[int]):
+        """The embeddings-level entry - the reference's vLLM hand-off (llm.py:482-510 passes `prompt_embeds` = lm_input (L, 896)
+        per request): the caller has assembled lm_input itself.  embeds: one (L_b, hidden) CUDA tensor per sequence, fp32 or
+        bf16 (all alike).  Prefill + the first token; `step` continues.  Returns (out_ids, out_n, raw_n) as `begin`."""
+        B = len(embeds)
+        dt = embeds[0].dtype
+        assert dt in (torch.float32, torch.bfloat16) and all(e.dtype == dt and e.dim() == 2 and e.shape[1] == self.cfg.hidden for e in embeds)
+        rows = torch.cat([e.to(self.device) for e in embeds], dim=0).contiguous()
+        out_ld = max(int(m) for m in max_len)
+        out = torch.zeros(B, out_ld, dtype=torch.int32, device=self.device)
+        out_n = torch.zeros(B, dtype=torch.int32, device=self.device)
+        raw_n = torch.zeros(B, dtype=torch.int32, device=self.device)
+        check(_lib.lib().fy_llm_prefill(self._h, rows.data_ptr(), 0 if dt == torch.float32 else 1, _lib.int_array([e.shape[0] for e in embeds]),
+                                        _lib.int_array(min_len), _lib.int_array(max_len), B, out.data_ptr(), out_ld, self._stream()))
+        self._gen = (out, out_n, raw_n, B)
+        return out, out_n, raw_n
+
     def step(self, n_steps: int):
         """Up to `n_steps` more tokens for the sequences still running -> (tokens kept so far per sequence, finished flags)."""
         out, out_n, raw_n, B = self._gen

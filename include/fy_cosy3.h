@@ -181,6 +181,16 @@ int fy_llm_generate(fy_llm* l, const int32_t* text_ids, const int32_t* n_text_al
 int fy_llm_begin(fy_llm* l, const int32_t* text_ids, const int32_t* n_text_all, const int32_t* prompt_speech,
                  const int32_t* n_prompt_speech, const int32_t* min_len, const int32_t* max_len, int32_t B,
                  int32_t* out_ids, int32_t out_ld, void* stream);
+/* The embeddings-level entry - the shape of the reference's engine-level LM swap (its vLLM path, cosyvoice/llm/llm.py:482-510:
+ * `add_request(uuid, {"prompt_embeds": lm_input (L, 896) bf16}, SamplingParams(stop_token_ids, min_tokens, max_tokens))`, then
+ * `step()` per token; weights exported with embed_tokens := speech_embedding, cosyvoice/utils/file_utils.py:92-118).  The HOST has
+ * assembled lm_input = [sos, embed_tokens(text), task_id, speech_embedding(prompt)] itself (llm.py:728-740); this call is
+ * fy_llm_begin without the assembly: prefill of the given rows + the first token, and fy_llm_step continues it (every next input is
+ * speech_embedding[id], gathered on the device).  embeds: device, the B sequences' rows packed back to back, (sum n_rows, hidden),
+ * dtype 0 = fp32, 1 = bf16; n_rows / min_len / max_len: host int32[B]; sequence b occupies slot b of the handle until the next
+ * fy_llm_begin / fy_llm_prefill.  Same ids as fy_llm_begin for the same rows (tests/test_llm_gpu.py).                          */
+int fy_llm_prefill(fy_llm* l, const void* embeds, int32_t dtype, const int32_t* n_rows, const int32_t* min_len, const int32_t* max_len,
+                   int32_t B, int32_t* out_ids, int32_t out_ld, void* stream);
 int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t out_ld, int32_t* out_n, int32_t* raw_n,
                 int32_t* finished, void* stream);
 /* Sampler used by the following fy_llm_generate calls.  kind 0: the greedy rule above.  kind 1: the reference's default,
@@ -242,6 +252,12 @@ int fy_audio_feat_run(fy_audio_feat* p, const float* wav, int64_t n_samples, flo
 size_t fy_allgather_audio_scratch_floats(int32_t world, int32_t b_max, int32_t s_max);
 int fy_allgather_audio(void* rccl_comm, int32_t world, const float* wav, int64_t wav_ld, const int32_t* n_samples, int32_t b,
                        int32_t b_max, int32_t s_max, float* scratch, float* wav_all, int32_t* n_all, void* stream);
+
+/* The record alone, for a host that gathers with its own collective (fangyan_tts_amd/parallel.py over torch.distributed): rec
+ * (b_max * s_max + b_max + 1 floats on the device) = the b rows of wav zero-padded / cut to (b_max, s_max), then count and lengths
+ * (min(n, s_max)) bit-cast to float.  n_samples_host: HOST int32[b]; they ride in the kernel arguments (no copy, no stream wait). */
+int fy_audio_record_pack(const float* wav, int64_t wav_ld, const int32_t* n_samples_host, int32_t b, int32_t b_max, int32_t s_max,
+                         float* rec, void* stream);
 
 /* ================================ tooling: synthetic tensors ================================
  * No pretrained checkpoint is reachable offline: tests and bench.py fill the model from a counter-based generator

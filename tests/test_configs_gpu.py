@@ -197,6 +197,44 @@ def test_instruct_batch8_full_size_against_oracle():
     m.close()
 
 
+def test_zero_shot_batch4_full_size_against_oracle():
+    """BASELINE.json configs[2] at full size (CosyVoice3-0.5B shapes, zero-shot with a 10 s prompt: 30 prompt-text ids + 250 prompt
+    speech tokens in the LM = a 296-row prefill per sequence, 500 prompt mel frames = DiT sequence 650, batch 4, 75 forced tokens -
+    the batch `bench.py`'s `zero_shot_b4` times): utterances 0 and 3 of the batch are held to the CPU oracle's whole per-utterance
+    path - ids exact, mel <= 4e-2 (bf16 flow decoder), waveform <= 2.5e-3 from the oracle vocoder run on the engine's own mel."""
+    import bench
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    from oracle import hift as ohift, pipeline as opipe
+    cfg = ModelCfg()
+    sd_llm = synth.state_dict_torch(cfg.llm.manifest(), DEV, skip=("lm_head",))
+    sd_flow = synth.state_dict_torch(cfg.flow.manifest(), DEV)
+    sd_hift = synth.state_dict_torch(cfg.hift.manifest(), DEV)
+    N, P, B = bench.N_TOK, 250, 4
+    noise = torch.from_numpy(synth.flow_rand_noise(2 * (P + N))).to(DEV)
+    ri = torch.from_numpy(synth.hift_rand_ini()).to(DEV)
+    sn = torch.from_numpy(synth.hift_sine_noise(2 * N * 480)).to(DEV)
+    m = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=DEV, max_batch=B, max_text=64, max_prompt_tokens=P, max_tokens=N,
+                        rand_noise=noise, rand_ini=ri, sine_noise=sn)
+    inputs = bench.zero_shot_inputs(cfg, B, P)
+    forced = [N] * B
+    wav, samples, toks = m.tts_batch(inputs, min_len=forced, max_len=forced)
+    mel = m.last_mel.cpu()
+    torch.set_num_threads(16)
+    PL = {k: v.cpu() for k, v in sd_llm.items()}
+    PF = {k: v.cpu() for k, v in sd_flow.items()}
+    PH = ohift.prepare({k: v.cpu().numpy() for k, v in sd_hift.items()})
+    for b in (0, 3):
+        ref = opipe.tts(inputs[b], PL, PF, PH, cfg, noise.cpu(), ri.cpu(), sn.cpu(), min_len=N, max_len=N)
+        assert toks[b].cpu().reshape(-1).tolist() == ref["tokens"].reshape(-1).tolist(), b
+        e_mel = maxerr(mel[b: b + 1, :, : 2 * N], ref["mel"])
+        S = samples[b]
+        ref_wav, _ = ohift.inference(mel[b: b + 1, :, : 2 * N], PH, cfg.hift, ri.cpu(), sn.cpu()[:, :S])
+        e_wav = maxerr(wav[b: b + 1, :S], ref_wav)
+        note("parity_configs.json", f"zero_shot_b4_full.{b}", [e_mel, e_wav])
+        assert e_mel <= 4e-2 and e_wav <= 2.5e-3, (b, e_mel, e_wav)
+    m.close()
+
+
 def test_bench_two_ranks_on_one_gpu_rehearsal():
     """BASELINE.json configs[3]'s launch path (`bench.py --gpus N`: self-started ranks, per-rank pipelines, one fused all-gather of
     the finished audio per step, max-over-ranks timing) rehearsed with two ranks that share this box's one GPU over gloo
@@ -221,8 +259,9 @@ def test_bench_two_ranks_on_one_gpu_rehearsal():
 def test_allgather_audio_c_entry_single_rank(tmp_path):
     """fy_allgather_audio (the C entry a host with its own RCCL communicator calls; Python hosts use parallel.gather_audio) on a
     one-rank communicator made with the RCCL copy torch ships: the fixed-size record is packed, gathered and unpacked - audio
-    zero-padded to (b_max, s_max), count and lengths behind it.  In a child process with a time limit: a communicator cannot be
-    made on every box (no usable network interface for the bootstrap), which skips the test instead of hanging the suite."""
+    zero-padded / cut to (b_max, s_max), count and lengths (min(n, s_max)) behind it.  In a child process with a time limit: a
+    bootstrap that never completes (no usable network interface) skips the test instead of hanging the suite; an error code
+    from RCCL fails it."""
     import os
     import subprocess
     import sys
@@ -237,17 +276,21 @@ rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
 class UID(C.Structure):
     _fields_ = [("b", C.c_char * 128)]
 uid = UID()
-if rccl.ncclGetUniqueId(C.byref(uid)) != 0:
-    print("SKIP ncclGetUniqueId"); sys.exit(0)
+rc = rccl.ncclGetUniqueId(C.byref(uid))
+if rc != 0:
+    print("FAIL ncclGetUniqueId returned", rc); sys.exit(1)
 comm = C.c_void_p()
 rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
-if rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) != 0:
-    print("SKIP ncclCommInitRank"); sys.exit(0)
+rc = rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0)
+if rc != 0:
+    print("FAIL ncclCommInitRank returned", rc); sys.exit(1)
+# world must equal the communicator's size (the gather writes nranks records into a scratch sized from `world`)
+assert L.fy_allgather_audio(comm, 2, 1, 1, 1, 0, 1, 1, 1, 1, 1, None) != 0 and b"ranks" in L.fy_last_error()
 dev = torch.device("cuda:0")
 b, b_max, s_max, ld = 3, 4, 1000, 1200
 g = torch.Generator().manual_seed(1)
 wav = torch.rand(b, ld, generator=g).to(dev)
-lens = torch.tensor([1000, 17, 640], dtype=torch.int32, device=dev)
+lens = torch.tensor([1100, 17, 640], dtype=torch.int32, device=dev)      # row 0 is longer than s_max: cut, and published as s_max
 scratch = torch.zeros(L.fy_allgather_audio_scratch_floats(1, b_max, s_max), device=dev)
 wav_all = torch.full((b_max, s_max), -7.0, device=dev)
 n_all = torch.full((1, b_max + 1), -1, dtype=torch.int32, device=dev)
@@ -269,6 +312,6 @@ print("OK")
     except subprocess.TimeoutExpired:
         pytest.skip("making a one-rank RCCL communicator did not finish on this box")
     assert r.returncode == 0, r.stderr[-2000:]
-    if "SKIP" in r.stdout:
-        pytest.skip(r.stdout.strip())
-    assert "OK" in r.stdout
+    # an ERROR from ncclGetUniqueId / ncclCommInitRank is a failure (the child says which); only the time-out above - a box whose
+    # bootstrap never completes - skips
+    assert "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -258,17 +258,21 @@ np.savez({str(tmp_path / 'out.npz')!r}, plain=out[0], stream=out[1])
         assert np.array_equal(here[1][b, :, :n], other["stream"][b, :, :n]), b
 
 
-def test_bench_sized_estimator_equals_pairs():
-    """The benchmark's estimator call (16 sequences x 400 frames: M = 6400 rows) picks other kernels than the small calls the
-    oracle tests make - 320x256 GEMM tiles with staggered wave groups for qkv, 16x16x32-MFMA tilings for the rest, one attention
-    workgroup per (sequence, head).  Every tiling accumulates K in the same order and both attention forms walk the key tiles
-    alike, so the big call must reproduce, bit for bit, what the same sequences give two at a time."""
-    eng, _, _ = make(FlowCfg(), max_batch=8, max_frames=400)
-    T, B2 = 400, 16
-    g = lambda name, shape: torch.from_numpy(synth.normal(f"in.bigest.{name}", shape)).to(DEV)
+@pytest.mark.parametrize("T,B2,lens", [
+    (400, 16, [400, 400, 377, 400, 256, 400, 400, 129, 400, 400, 400, 31, 400, 400, 390, 400]),     # configs[1]: M = 6400
+    (650, 8, [650, 650, 611, 650, 650, 333, 650, 650]),                                             # configs[2]: M = 5200
+])
+def test_bench_sized_estimator_equals_pairs(T, B2, lens):
+    """The benchmark's estimator calls - configs[1]: 16 sequences x 400 frames (M = 6400 rows); configs[2], zero-shot batch 4 behind
+    a 10 s prompt: 8 sequences x 650 frames (M = 5200) - pick other kernels than the small calls the oracle tests make: 320x256 GEMM
+    tiles with staggered wave groups for qkv, 16x16x32-MFMA tilings for the rest (other tile counts at M = 5200: 21 row panels of
+    256, 41 of 128, 17 of 320, the last ones ragged), one attention workgroup per (sequence, head) at 400 frames and the 4-wave
+    form at 650.  Every tiling accumulates K in the same order and both attention forms walk the key tiles alike, so the big call
+    must reproduce, bit for bit, what the same sequences give two at a time."""
+    eng, _, _ = make(FlowCfg(), max_batch=B2 // 2, max_frames=T)
+    g = lambda name, shape: torch.from_numpy(synth.normal(f"in.bigest.{T}.{name}", shape)).to(DEV)
     x, mu, cond, spks = g("x", (B2, 80, T)), g("mu", (B2, 80, T)), g("cond", (B2, 80, T)), g("spks", (B2, 80))
     t = torch.full((B2,), 0.3, device=DEV)
-    lens = [400, 400, 377, 400, 256, 400, 400, 129, 400, 400, 400, 31, 400, 400, 390, 400]
     mask = torch.zeros(B2, 1, T, device=DEV)
     for b, n in enumerate(lens):
         mask[b, 0, :n] = 1

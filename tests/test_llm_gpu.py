@@ -235,6 +235,44 @@ def test_begin_step_equals_generate(tiny):
             tiny.set_sampler("greedy")
 
 
+def test_prefill_from_embeddings_equals_begin(tiny):
+    """fy_llm_prefill - the embeddings-level entry shaped like the reference's vLLM hand-off (llm.py:482-510: the host passes
+    `prompt_embeds` = lm_input (L, hidden)) - against fy_llm_begin on the same sequences: the host assembles lm_input =
+    [speech_embedding[sos], embed_tokens(prompt_text + text), speech_embedding[task_id], speech_embedding(prompt_speech)]
+    (llm.py:728-740) from the state dict, fp32 and bf16 (embed_tokens is bf16 in the engine, so fp32 rows carry the same values;
+    bf16 rows round the fp32 speech embeddings, which the synthetic weights make bf16-exact) - identical ids, batched, and the
+    reference fixture's ids for case 0."""
+    from oracle.llm import silent_filter
+    cfg = tiny.cfg
+    cases = [(12, 8, 0), (16, 4, 10)]
+    texts, ptexts, ptoks = (list(x) for x in zip(*[llm_case(cfg, *c, "%d_%d_%d" % c) for c in cases]))
+    cap = [min(20 * len(t), 400) for t in texts]
+    mn = [2 * len(t) for t in texts]
+    whole, whole_n, _ = tiny.generate(texts, ptexts, ptoks, max_len=cap)
+    whole, whole_n = whole.cpu().clone(), whole_n.cpu().tolist()
+    sd = synth.state_dict_torch(cfg.manifest(), DEV, skip=("lm_head",))       # the deterministic synthetic weights the engine was built from
+    emb_tok = sd["llm.model.model.embed_tokens.weight"].to(torch.bfloat16).float()       # the engine keeps embed_tokens in bf16
+    emb_sp = sd["speech_embedding.weight"]
+    for dt in (torch.float32, torch.bfloat16):
+        rows = []
+        for b in range(len(cases)):
+            ids = torch.tensor(list(ptexts[b]) + list(texts[b]), dtype=torch.long, device=emb_tok.device)
+            parts = [emb_sp[cfg.speech_tokens: cfg.speech_tokens + 1], emb_tok[ids], emb_sp[cfg.speech_tokens + 2: cfg.speech_tokens + 3]]
+            if len(ptoks[b]):
+                parts.append(emb_sp[torch.tensor(list(ptoks[b]), dtype=torch.long, device=emb_sp.device)])
+            rows.append(torch.cat(parts, dim=0).to(dt))
+        out, _, _ = tiny.prefill_embeds(rows, mn, cap)
+        n, fin = tiny.step(0)
+        while not all(fin):
+            n, fin = tiny.step(50)
+        assert n == whole_n, (dt, n, whole_n)
+        out = out.cpu()
+        for b in range(len(cases)):
+            assert out[b, : n[b]].tolist() == whole[b, : n[b]].tolist(), (dt, b)
+    f = golden("llm_tiny.npz")
+    assert out[0, : n[0]].tolist() == silent_filter(f["c%d_%d_%d.tokens" % cases[0]].tolist())
+
+
 def _ras_rows(cases, n_rows):
     u = np.zeros((n_rows, 4096), dtype=np.float32)
     for b, c in enumerate(cases):

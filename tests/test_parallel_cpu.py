@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from fangyan_tts_amd.parallel import gather_audio, shard_range
+from fangyan_tts_amd.parallel import gather_audio, plan_order, plan_shards, shard_range, unshard
 
 
 def test_shard_range_partitions():
@@ -66,4 +66,88 @@ def test_gather_audio_gloo_world2():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world))
+
+
+def test_plan_shards_is_a_balanced_partition():
+    """Length-sorted sharding: every utterance exactly once; a batch holds neighbours of the sorted order; the
+    ranks' padded costs differ by at most one batch; the plan is a pure function of the costs (every rank computes the same)."""
+    import random
+    rnd = random.Random(7)
+    for n, world, batch in ((64, 8, 8), (64, 8, None), (61, 8, 8), (5, 2, None), (3, 4, None), (128, 8, 8), (1, 1, None)):
+        costs = [rnd.randint(10, 40) for _ in range(n)]
+        plan = plan_shards(costs, world, batch)
+        assert plan == plan_shards(list(costs), world, batch)
+        flat = plan_order(plan)
+        assert sorted(flat) == list(range(n))
+        bsz = batch or max(1, -(-n // world))
+        for rank in plan:
+            for b in rank:
+                assert 1 <= len(b) <= bsz
+        batches = [b for rank in plan for b in rank]
+        # neighbours in the sorted order: the ranges of two batches do not interleave
+        spans = sorted((min(costs[i] for i in b), max(costs[i] for i in b)) for b in batches)
+        for (lo0, hi0), (lo1, hi1) in zip(spans, spans[1:]):
+            assert hi0 <= lo1 or (lo0 == lo1)
+        load = [sum(max(costs[i] for i in b) * len(b) for b in rank) for rank in plan]
+        biggest = max(max(costs[i] for i in b) * len(b) for b in batches)
+        assert max(load) - min(load) <= biggest
+        counts = [len(rank) for rank in plan]
+        assert max(counts) - min(counts) <= 1 or batch is None
+        # against contiguous blocks in input order: the padded work (sum over batches of max x size) never grows
+        naive = 0
+        for r in range(world):
+            idx = list(shard_range(n, r, world))
+            for o in range(0, len(idx), bsz):
+                blk = idx[o: o + bsz]
+                naive += max(costs[i] for i in blk) * len(blk)
+        assert sum(load) <= naive
+    # unshard is the inverse permutation
+    costs = [5, 9, 1, 7, 3, 8, 2]
+    plan = plan_shards(costs, 3, 2)
+    rows = [[("utt", i) for b in rank for i in b] for rank in plan]
+    assert unshard(rows, plan) == [("utt", i) for i in range(len(costs))]
+
+
+def _worker_sorted(rank, world, port, ret):
+    """Ragged utterances, length-sorted plan, two steps through ONE preallocated gather; rows go back to input order."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_utts, batch = 11, 3
+    lens_all = [700 + 53 * ((7 * i) % 11) for i in range(n_utts)]            # ragged, not monotone in i
+    plan = plan_shards(lens_all, world, batch)
+    steps = max(len(p) for p in plan)
+    got = {}
+    ok = True
+    for k in range(steps):
+        mine = plan[rank][k] if k < len(plan[rank]) else []
+        lens = [lens_all[i] for i in mine]
+        wav = torch.zeros(len(mine), 1300)
+        for j, i in enumerate(mine):
+            wav[j, : lens[j]] = torch.arange(lens[j], dtype=torch.float32) + 10000.0 * i
+        out, per_rank = gather_audio(wav, lens, b_max=batch, s_max=1300)
+        for r in range(world):
+            idx = plan[r][k] if k < len(plan[r]) else []
+            ok &= len(per_rank[r]) == len(idx)
+            for j, i in enumerate(idx):
+                got[i] = (per_rank[r][j], out[r * batch + j].clone())
+    from fangyan_tts_amd import parallel
+    ok &= len(parallel._gathers) == 1 and steps >= 2          # one set of buffers served every step
+    ok &= sorted(got) == list(range(n_utts))
+    for i in range(n_utts):
+        n, row = got[i]
+        ok &= n == lens_all[i]
+        ok &= bool(torch.equal(row[:n], torch.arange(n, dtype=torch.float32) + 10000.0 * i)) and float(row[n:].abs().max()) == 0.0
+    ret[rank] = ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sorted_shards_gather_gloo_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_sorted, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret[r] for r in range(world))
