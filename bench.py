@@ -186,6 +186,31 @@ def zero_shot_inputs(cfg, B=4, P=250):
     """configs[2]'s synthetic batch: 14 text ids behind 30 prompt-text ids, P prompt speech tokens (LM and flow), 2 P prompt mel frames."""
     import numpy as np
     from fangyan_tts_amd import synth
+    hi = min(cfg.llm.vocab, 151643)
+    inputs = []
+    for b in range(B):
+        tag = f"bench.zs.u{b}"
+        ptok = torch.from_numpy(synth.randint(tag + ".ptok", (1, P), 0, cfg.flow.vocab))
+        inputs.append({"text": torch.from_numpy(synth.randint(tag + ".text", (1, 14), 0, hi)),
+                       "prompt_text": torch.from_numpy(synth.randint(tag + ".ptext", (1, 30), 0, hi)),
+                       "llm_prompt_speech_token": ptok, "flow_prompt_speech_token": ptok,
+                       "prompt_speech_feat": torch.from_numpy(np.clip(synth.normal(tag + ".pfeat", (1, 2 * P, 80), -5.0, 2.0), -11.5, 2.0)),
+                       "flow_embedding": torch.from_numpy(synth.normal(tag + ".spk", (1, 192)))})
+    return inputs
+
+
+def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib, steps=3):
+    """BASELINE.json configs[2] as a secondary object: zero-shot with a 10 s prompt (30 prompt-text ids, 250 prompt speech
+    tokens in the LM = a ~296-row prefill per sequence, 500 prompt mel frames: DiT sequence 650), batch 4, 75 forced tokens,
+    steps one after the other on one stream."""
+    from fangyan_tts_amd import synth
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    B, P = 4, 250
+    noise = torch.from_numpy(synth.flow_rand_noise(2 * (P + N_TOK))).to(dev)
+    ri = torch.from_numpy(synth.hift_rand_ini()).to(dev)
+    sn = torch.from_numpy(synth.hift_sine_noise(2 * N_TOK * 480)).to(dev)
+    m = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=B, max_text=64, max_prompt_tokens=P, max_tokens=N_TOK,
+                        rand_noise=noise, rand_ini=ri, sine_noise=sn)
     inputs = zero_shot_inputs(cfg, B, P)
     forced = [N_TOK] * B
     m.tts_batch(inputs, min_len=forced, max_len=forced)

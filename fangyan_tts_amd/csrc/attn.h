@@ -5,6 +5,11 @@
 // chunk > 0 adds the streaming block-causal mask key < (query/chunk + 1)*chunk.
 int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st);
 
+// The split-operand form (fp32-class flow decoder): q, k, v and the output as x = hi + lo, two bf16 planes each, same layouts;
+// three MFMAs per product keep the hi x hi, hi x lo and lo x hi terms, softmax in fp32.
+int dit_attention_split(const bf16_t* qkv_hi, const bf16_t* qkv_lo, bf16_t* out_hi, bf16_t* out_lo, const int* seq_len, int nseq, int Tmax, int H, int chunk,
+                        hipStream_t st);
+
 // fp32 GQA attention over the KV cache, head_dim 64.  q: [R][q_ld]; K/V cache: [seq][Hk][max_ctx][64];
 // row r attends positions 0..row_pos[r] of sequence row_seq[r].
 int llm_attention(const float* q, int q_ld, const float* Kc, const float* Vc, const int* row_seq, const int* row_pos, float* out,

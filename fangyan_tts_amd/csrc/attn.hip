@@ -8,6 +8,7 @@
 //                     (transformers Qwen2Attention as called from llm/llm.py:246-258).
 #include "attn.h"
 #include "gemv32.h"
+#include <algorithm>
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
@@ -230,6 +231,207 @@ int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, 
     }
     HIP_TRY(hipGetLastError());
     return FY_OK;
+}
+
+// -----------------------------------------------------------------------------------------------
+// The split-operand form for the fp32-class flow decoder (FY_PRECISE): q, k, v arrive as x = hi + lo, two bf16 planes written by
+// the projection's epilogue (16 mantissa bits), and every product keeps the three leading terms of (a_hi + a_lo)(b_hi + b_lo):
+//   S^T = K_hi Q_hi^T + K_hi Q_lo^T + K_lo Q_hi^T;   P = softmax(S) in fp32, split again p = p_hi + p_lo;
+//   O^T = V_hi^T P_hi^T + V_lo^T P_hi^T + V_hi^T P_lo^T            (the dropped lo x lo terms are 2^-16 of a term each)
+// - three MFMAs where the bf16 kernel has one, instead of the fp32 VALU kernel this replaces (which re-read a sequence's keys
+// from L2 per query: 104-155 us per call against ~30).  Same tiling as dit_attention_k: scores transposed so a lane owns one
+// query, the probabilities in registers are the B operand of the second product, V^T by ds_read_b64_tr_b16; K/V tiles of both
+// planes double-buffered in LDS (86 KB: one workgroup of up to 8 waves per CU, two waves per SIMD, Q fragments in registers).
+// qkv_hi / qkv_lo: bf16 [nseq*Tmax][3*H*64] as [q | k | v]; out_hi / out_lo: bf16 [nseq*Tmax][H*64]
+template <int AT_NW>
+__global__ __launch_bounds__(AT_NW * 64) void dit_attention_split_k(const bf16_t* __restrict__ qkv_hi, const bf16_t* __restrict__ qkv_lo,
+                                                                     bf16_t* __restrict__ out_hi, bf16_t* __restrict__ out_lo,
+                                                                     const int* __restrict__ seq_len, int Tmax, int H, int chunk, float scale_log2) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t at_smem[];
+    constexpr int KSZ = 64 * AT_KP, VSZ = 64 * AT_VP, BUF = 2 * KSZ + 2 * VSZ;       // one buffer: K_hi, K_lo, V_hi, V_lo
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (AT_NW * 32);
+    const int len = seq_len[s];
+    if (q0 >= len) return;
+    const int ld = 3 * H * AT_D;
+    const long sbase = (long)s * Tmax * ld;
+    const int lr = lane & 31, hf = lane >> 5;
+    const int qrow = q0 + wid * 32 + lr;                     // this lane's query
+    frag_ab qh[4], ql[4];                                    // B[k = 16ks + 8hf + j][col = query], both planes
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const long o = sbase + (long)min(qrow, len - 1) * ld + h * AT_D + ks * 16 + hf * 8;
+        qh[ks] = *reinterpret_cast<const frag_ab*>(qkv_hi + o);
+        ql[ks] = *reinterpret_cast<const frag_ab*>(qkv_lo + o);
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    int kend = len;
+    if (chunk > 0) kend = min(len, ((min(q0 + AT_NW * 32 - 1, len - 1) / chunk) + 1) * chunk);
+    const int lim = chunk > 0 ? min(len, ((min(qrow, len - 1) / chunk) + 1) * chunk) : len;   // keys < lim are visible to this query
+    // a tile = 4 planes x 512 16-byte chunks (64 keys x 8 chunks): K_hi, K_lo, V_hi, V_lo; chunk c = tid + i * threads
+    constexpr int NT = AT_NW * 64, NLD = (2048 + NT - 1) / NT;
+    uint4 kvreg[NLD];
+    auto load_kv = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + i * NT, pl = c >> 9, idx = c & 511, key = idx >> 3, dc = (idx & 7) * 8;
+            if (2048 % NT == 0 || c < 2048) {
+                const bool ok = k0 + key < len;
+                const bf16_t* src = (pl & 1) ? qkv_lo : qkv_hi;
+                kvreg[i] = *reinterpret_cast<const uint4*>(src + sbase + (long)min(k0 + key, len - 1) * ld + h * AT_D + dc + (pl < 2 ? 1 : 2) * H * AT_D);
+                if (!ok) kvreg[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto store_kv = [&](int buf) {
+        bf16_t* b = at_smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int c = tid + i * NT, pl = c >> 9, idx = c & 511, key = idx >> 3, dc = (idx & 7) * 8;
+            if (2048 % NT == 0 || c < 2048) {
+                if (pl < 2) *reinterpret_cast<uint4*>(b + pl * KSZ + key * AT_KP + dc) = kvreg[i];
+                else *reinterpret_cast<uint4*>(b + 2 * KSZ + (pl - 2) * VSZ + key * AT_VP + dc) = kvreg[i];
+            }
+        }
+    };
+    const int gi = lane >> 4, li = lane & 15;
+    const int v_off = (4 * hf + (li >> 2)) * AT_VP + 16 * (gi & 1) + 4 * (li & 3);
+    const bool wave_live = q0 + wid * 32 < len;              // a wave past the sequence end only helps staging
+    load_kv(0);
+    store_kv(0);
+    __syncthreads();
+    for (int k0 = 0, it = 0; k0 < kend; k0 += 64, ++it) {
+        const bf16_t* Kh = at_smem + (it & 1) * BUF;
+        const bf16_t* Kl = Kh + KSZ;
+        const bf16_t* Vh = Kh + 2 * KSZ;
+        const bf16_t* Vl = Vh + VSZ;
+        const bool more = k0 + 64 < kend;
+        if (more) load_kv(k0 + 64);
+        if (wave_live) {
+        f32x16 sc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int ko = (kt * 32 + lr) * AT_KP + ks * 16 + hf * 8;
+                const frag_ab kh = *reinterpret_cast<const frag_ab*>(Kh + ko);
+                const frag_ab kl = *reinterpret_cast<const frag_ab*>(Kl + ko);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[ks], sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[ks], sc[kt], 0, 0, 0);
+                sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[ks], sc[kt], 0, 0, 0);
+            }
+        }
+        frag_ab ph[2][2], pl[2][2];                          // P^T = p_hi + p_lo as B operands: [kt][k-step s] = registers 8s .. 8s+7
+        float mx = -1e30f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+                const float v = key < lim ? sc[kt][r] * scale_log2 : -1e30f;
+                sc[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = sc[kt][r] > -1e29f ? exp2f(sc[kt][r] - mnew) : 0.f;
+                ps += p;
+                const __bf16 hb = (__bf16)p;
+                ph[kt][r >> 3][r & 7] = hb;
+                pl[kt][r >> 3][r & 7] = (__bf16)(p - (float)hb);
+            }
+        m_run = mnew;
+        ps += __shfl_xor(ps, 32, 64);
+        l_run = l_run * alpha + ps;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int vo = (kt * 32 + st * 16) * AT_VP + dt * 32 + v_off;
+                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + vo));
+                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vh + vo + 8 * AT_VP));
+                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + vo));
+                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(Vl + vo + 8 * AT_VP));
+                    const bf16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    const bf16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(frag_ab, vh), ph[kt][st], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(frag_ab, vl), ph[kt][st], o[dt], 0, 0, 0);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(frag_ab, vh), pl[kt][st], o[dt], 0, 0, 0);
+                }
+        }
+        if (more) store_kv((it + 1) & 1);                    // that buffer was last read before the previous barrier
+        __syncthreads();
+    }
+    if (qrow >= len) return;
+    const float inv = 1.f / l_run;
+    const long oo = ((long)s * Tmax + qrow) * (H * AT_D) + h * AT_D;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            float v[4];
+            bf16_t hb[4], lb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = o[dt][rb * 4 + j] * inv;
+                hb[j] = f32_to_bf16(v[j]);
+                lb[j] = f32_to_bf16(v[j] - bf16_to_f32(hb[j]));
+            }
+            uint2 a, b;
+            a.x = (uint32_t)hb[0] | ((uint32_t)hb[1] << 16); a.y = (uint32_t)hb[2] | ((uint32_t)hb[3] << 16);
+            b.x = (uint32_t)lb[0] | ((uint32_t)lb[1] << 16); b.y = (uint32_t)lb[2] | ((uint32_t)lb[3] << 16);
+            *reinterpret_cast<uint2*>(out_hi + oo + dt * 32 + rb * 8 + hf * 4) = a;
+            *reinterpret_cast<uint2*>(out_lo + oo + dt * 32 + rb * 8 + hf * 4) = b;
+        }
+}
+
+template <int W>
+static int dit_attention_split_launch(const bf16_t* qh, const bf16_t* ql, bf16_t* oh, bf16_t* ol, const int* seq_len, int nseq, int Tmax, int H, int chunk,
+                                      dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)2 * (2 * 64 * AT_KP + 2 * 64 * AT_VP) * sizeof(bf16_t);      // 86 016 B: above the 64 KB default
+    // set once per process and kernel (a thread-safe function-local static: several flow handles may make their first call at once)
+    static const hipError_t attr = hipFuncSetAttribute((const void*)dit_attention_split_k<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    HIP_TRY(attr);
+    hipLaunchKernelGGL((dit_attention_split_k<W>), grid, dim3(W * 64), lds, st, qh, ql, oh, ol, seq_len, Tmax, H, chunk, 0.125f * 1.4426950408889634f);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+int dit_attention_split(const bf16_t* qkv_hi, const bf16_t* qkv_lo, bf16_t* out_hi, bf16_t* out_lo, const int* seq_len, int nseq, int Tmax, int H, int chunk,
+                        hipStream_t st) {
+    FY_CHECK(qkv_hi && qkv_lo && out_hi && out_lo && seq_len && nseq >= 1 && Tmax >= 1 && H >= 1, FY_ERR_ARG, "dit_attention_split: bad arguments");
+    // 32 queries per wave, up to 8 waves per workgroup, the waves spread evenly over the workgroups of a (sequence, head); at least 4
+    // (waves past the sequence end help staging the 4-plane K/V tiles)
+    const int nw = cdiv(Tmax, 32), nblk = cdiv(nw, 8), W = std::max(4, cdiv(nw, nblk));
+    dim3 grid(cdiv(nw, W), H, nseq);
+    switch (W) {
+        case 4: return dit_attention_split_launch<4>(qkv_hi, qkv_lo, out_hi, out_lo, seq_len, nseq, Tmax, H, chunk, grid, st);
+        case 5: return dit_attention_split_launch<5>(qkv_hi, qkv_lo, out_hi, out_lo, seq_len, nseq, Tmax, H, chunk, grid, st);
+        case 6: return dit_attention_split_launch<6>(qkv_hi, qkv_lo, out_hi, out_lo, seq_len, nseq, Tmax, H, chunk, grid, st);
+        case 7: return dit_attention_split_launch<7>(qkv_hi, qkv_lo, out_hi, out_lo, seq_len, nseq, Tmax, H, chunk, grid, st);
+        default: return dit_attention_split_launch<8>(qkv_hi, qkv_lo, out_hi, out_lo, seq_len, nseq, Tmax, H, chunk, grid, st);
+    }
 }
 
 // -----------------------------------------------------------------------------------------------

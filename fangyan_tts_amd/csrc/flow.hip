@@ -37,8 +37,9 @@ struct fy_flow {
     int *tok_all, *seq_len, *blen;     // blen: [5][max_batch] = n_all tokens, T, pmel, prompt tokens, tokens PreLookahead outputs
     float *emb, *pre_a, *mu_tok, *spks, *x, *mu, *cond, *h, *c1, *v, *temb, *tsil, *gpart;
     bf16_t *a_in, *xn, *qkv, *ao, *ff;
-    // fp32 operands of the fp32-class mode (FY_PRECISE), allocated on its first use
-    float *a_in32 = nullptr, *xn32 = nullptr, *qkv32 = nullptr, *ao32 = nullptr, *ff32 = nullptr;
+    // lo planes of the fp32-class mode (FY_PRECISE): every GEMM operand travels as x = hi + lo, the hi plane in the default mode's
+    // own buffer (a_in, xn, qkv, ao, ff: hi = bf16(x) is exactly what the default mode stores), the lo plane here; allocated on first use
+    bf16_t *a_in_lo = nullptr, *xn_lo = nullptr, *qkv_lo = nullptr, *ao_lo = nullptr, *ff_lo = nullptr;
     ~fy_flow() { conv_free(pre1); conv_free(pre2); conv_free(pos1); conv_free(pos2); }
 };
 
@@ -100,7 +101,7 @@ __global__ void flow_setup_k(const float* __restrict__ mu_tok, const float* __re
 // InputEmbedding concat [x, cond, mu, spks] (dit.py:91-96) for the conditional row and [x, 0, 0, 0]
 // for the CFG row (flow_matching.py:95-101), as the bf16 A operand of the input projection.
 __global__ void dit_assemble_k(const float* __restrict__ x, const float* __restrict__ cond, const float* __restrict__ mu, const float* __restrict__ spks,
-                               const int* __restrict__ T, bf16_t* __restrict__ a, float* __restrict__ a32, int Tmax, int C) {
+                               const int* __restrict__ T, bf16_t* __restrict__ a, bf16_t* __restrict__ a_lo, int Tmax, int C) {
     int s = blockIdx.y, t = blockIdx.x, b = s >> 1, cfg = s & 1;
     int i = threadIdx.x;                     // 0 .. 4C
     if (i >= 4 * C) return;
@@ -111,17 +112,18 @@ __global__ void dit_assemble_k(const float* __restrict__ x, const float* __restr
         if (part == 0) v = x[o + c];
         else if (!cfg) v = part == 1 ? cond[o + c] : (part == 2 ? mu[o + c] : spks[(long)b * C + c]);
     }
-    if (a32) a32[((long)s * Tmax + t) * 4 * C + i] = v;          // fp32-class mode (FY_PRECISE): the operand is split on the fly
-    else a[((long)s * Tmax + t) * 4 * C + i] = f32_to_bf16(v);
+    const bf16_t hb = f32_to_bf16(v);
+    a[((long)s * Tmax + t) * 4 * C + i] = hb;
+    if (a_lo) a_lo[((long)s * Tmax + t) * 4 * C + i] = f32_to_bf16(v - bf16_to_f32(hb));      // fp32-class mode (FY_PRECISE): x = hi + lo
 }
 
 // LayerNorm(eps 1e-6, no affine) * (1 + scale) + shift -> bf16 (modules.py:238-243, 524, 262-264). One wave per row.
 __global__ __launch_bounds__(256) void ln_mod_k(const float* __restrict__ h, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                bf16_t* __restrict__ out, float* __restrict__ out32, int M, int D) {
+                                                bf16_t* __restrict__ out, bf16_t* __restrict__ out_lo, int M, int D) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= M) return;
     const float* p = h + (long)row * D;
-    if ((D & 255) == 0 && D <= 1024 && !out32) {                       // 16-byte loads, 8-byte stores: four columns per lane and pass
+    if ((D & 255) == 0 && D <= 1024) {                       // 16-byte loads, 8-byte stores: four columns per lane and pass
         const int per4 = D / 256;                            // <= 4
         float4 v[4];
         float s = 0.f;
@@ -144,12 +146,18 @@ __global__ __launch_bounds__(256) void ln_mod_k(const float* __restrict__ h, con
             if (i < per4) {
                 const int c = (lane + 64 * i) * 4;
                 const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+                const float y0 = (v[i].x - mean) * rstd * (1.f + sc.x) + sh.x, y1 = (v[i].y - mean) * rstd * (1.f + sc.y) + sh.y;
+                const float y2 = (v[i].z - mean) * rstd * (1.f + sc.z) + sh.z, y3 = (v[i].w - mean) * rstd * (1.f + sc.w) + sh.w;
+                const bf16_t h0 = f32_to_bf16(y0), h1 = f32_to_bf16(y1), h2 = f32_to_bf16(y2), h3 = f32_to_bf16(y3);
                 uint2 pk;
-                pk.x = (uint32_t)f32_to_bf16((v[i].x - mean) * rstd * (1.f + sc.x) + sh.x) |
-                       ((uint32_t)f32_to_bf16((v[i].y - mean) * rstd * (1.f + sc.y) + sh.y) << 16);
-                pk.y = (uint32_t)f32_to_bf16((v[i].z - mean) * rstd * (1.f + sc.z) + sh.z) |
-                       ((uint32_t)f32_to_bf16((v[i].w - mean) * rstd * (1.f + sc.w) + sh.w) << 16);
+                pk.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                pk.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
                 *reinterpret_cast<uint2*>(out + (long)row * D + c) = pk;
+                if (out_lo) {                                    // fp32-class mode: the lo plane of x = hi + lo
+                    pk.x = (uint32_t)f32_to_bf16(y0 - bf16_to_f32(h0)) | ((uint32_t)f32_to_bf16(y1 - bf16_to_f32(h1)) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(y2 - bf16_to_f32(h2)) | ((uint32_t)f32_to_bf16(y3 - bf16_to_f32(h3)) << 16);
+                    *reinterpret_cast<uint2*>(out_lo + (long)row * D + c) = pk;
+                }
             }
         return;
     }
@@ -168,52 +176,11 @@ __global__ __launch_bounds__(256) void ln_mod_k(const float* __restrict__ h, con
         if (i < per) {
             int c = lane + 64 * i;
             const float y = (v[i] - mean) * rstd * (1.f + scale[c]) + shift[c];
-            if (out32) out32[(long)row * D + c] = y; else out[(long)row * D + c] = f32_to_bf16(y);
+            const bf16_t hb = f32_to_bf16(y);
+            out[(long)row * D + c] = hb;
+            if (out_lo) out_lo[(long)row * D + c] = f32_to_bf16(y - bf16_to_f32(hb));
         }
     }
-}
-
-// fp32 attention for the fp32-class mode (FY_PRECISE): one wave per query row; qkv fp32 [row][3*inner] = [q | k | v],
-// key-padding mask (key < len), optional chunk mask key < (query / chunk + 1) * chunk, rows beyond the length zeroed
-// (modules.py:391-401).  A verification path: no tiling, every query re-reads its sequence's keys from L2.
-__global__ __launch_bounds__(256) void dit_attention_f32_k(const float* __restrict__ qkv, float* __restrict__ out, const int* __restrict__ seq_len,
-                                                            int Tmax, int H, int chunk) {
-    extern __shared__ float at_sh[];                        // [4 waves][64 q + Tmax scores]
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + wid, h = blockIdx.y, s = blockIdx.z;
-    if (t >= Tmax) return;
-    const int inner = H * 64, ld = 3 * inner, len = seq_len[s];
-    float* qs = at_sh + wid * (64 + Tmax);
-    float* sc = qs + 64;
-    float* o = out + ((long)s * Tmax + t) * inner + h * 64;
-    if (t >= len) { o[lane] = 0.f; return; }
-    const float* base = qkv + (long)s * Tmax * ld;
-    qs[lane] = base[(long)t * ld + h * 64 + lane];
-    __builtin_amdgcn_wave_barrier();
-    const int lim = chunk > 0 ? min(len, (t / chunk + 1) * chunk) : len;
-    float mx = -3.0e38f;
-    for (int j = lane; j < lim; j += 64) {
-        const float4* kr = reinterpret_cast<const float4*>(base + (long)j * ld + inner + h * 64);
-        float a = 0.f;
-#pragma unroll
-        for (int d4 = 0; d4 < 16; ++d4) {
-            const float4 k4 = kr[d4];
-            a = fmaf(qs[d4 * 4 + 0], k4.x, a); a = fmaf(qs[d4 * 4 + 1], k4.y, a);
-            a = fmaf(qs[d4 * 4 + 2], k4.z, a); a = fmaf(qs[d4 * 4 + 3], k4.w, a);
-        }
-        a *= 0.125f;
-        sc[j] = a;
-        mx = fmaxf(mx, a);
-    }
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < lim; j += 64) { const float p = expf(sc[j] - mx); sc[j] = p; sum += p; }
-    sum = wave_sum(sum);
-    __builtin_amdgcn_wave_barrier();
-    float acc = 0.f;
-    const float* vb = base + 2 * inner + h * 64 + lane;
-    for (int j = 0; j < lim; ++j) acc = fmaf(sc[j], vb[(long)j * ld], acc);
-    o[lane] = acc / sum;
 }
 
 // CFG mix and Euler update, flow_matching.py:114-118
@@ -421,16 +388,16 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
 
 extern "C" void fy_flow_destroy(fy_flow* f) { delete f; }
 
-// fp32 operand buffers of the fp32-class mode, sized for the handle's capacity, on first use
+// lo planes of the fp32-class mode, sized for the handle's capacity, on first use
 static int ensure_precise(fy_flow* f) {
     const fy_flow_config& c = f->cfg;
     const size_t M = (size_t)2 * f->max_batch * f->Tmax, D = c.dim, inner = (size_t)c.heads * c.head_dim, FF = D * c.ff_mult;
     // buffer by buffer, so a call after a partial failure (out of memory) allocates only what is still missing
-    if (!f->a_in32) FY_TRY(f->pool.alloc(&f->a_in32, M * 4 * c.mel));
-    if (!f->qkv32) FY_TRY(f->pool.alloc(&f->qkv32, M * 3 * inner));
-    if (!f->ao32) FY_TRY(f->pool.alloc(&f->ao32, M * inner));
-    if (!f->ff32) FY_TRY(f->pool.alloc(&f->ff32, M * FF));
-    if (!f->xn32) FY_TRY(f->pool.alloc(&f->xn32, M * D));
+    if (!f->a_in_lo) FY_TRY(f->pool.alloc(&f->a_in_lo, M * 4 * c.mel));
+    if (!f->qkv_lo) FY_TRY(f->pool.alloc(&f->qkv_lo, M * 3 * inner));
+    if (!f->ao_lo) FY_TRY(f->pool.alloc(&f->ao_lo, M * inner));
+    if (!f->ff_lo) FY_TRY(f->pool.alloc(&f->ff_lo, M * FF));
+    if (!f->xn_lo) FY_TRY(f->pool.alloc(&f->xn_lo, M * D));
     return FY_OK;
 }
 
@@ -440,14 +407,15 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
     const fy_flow_config& c = f->cfg;
     const int D = c.dim, C = c.mel, inner = c.heads * c.head_dim, FF = D * c.ff_mult;
     const int M = nseq * Tmax;
-    // FY_PRECISE: every linear takes its activations in fp32 and splits them into bf16 hi + lo on the fly (the weights are
-    // bf16-exact in the tests, so the products carry ~16 mantissa bits into an fp32 accumulation), the attention runs in
-    // fp32, GELU uses the exact tanh: an fp32-class estimator that meets the reference's own bar for swapping the estimator
-    // (rtol 1e-2 / atol 1e-4, cosyvoice/bin/export_onnx.py:109).
+    // FY_PRECISE: every GEMM operand travels as x = hi + lo, two bf16 planes written by its producer (16 mantissa bits; the weights
+    // are bf16-exact in the tests), two MFMAs per fragment into an fp32 accumulator on the same LDS-DMA ring kernel as the default
+    // mode (gemm_split); attention keeps the three leading terms of each split product, softmax in fp32 (dit_attention_split); GELU
+    // uses the exact tanh: an fp32-class estimator that meets the reference's own bar for swapping the estimator (rtol 1e-2 /
+    // atol 1e-4, cosyvoice/bin/export_onnx.py:109) at ~2x the default mode's MFMA work.
     const bool pr = (flags & FY_PRECISE) != 0;
     GemmEpi e;
     e.bias = f->b_in; e.out = f->h; e.out_bf16 = 0; e.ldc = D;
-    if (pr) FY_TRY(gemm_f32a_precise(f->a_in32, 4 * C, f->w_in, M, D, 4 * C, e, st));
+    if (pr) { e.a_lo = f->a_in_lo; FY_TRY(gemm_split(f->a_in, 4 * C, f->w_in, M, D, 4 * C, e, st)); }
     else FY_TRY(gemm_bf16(f->a_in, 4 * C, f->w_in, M, D, 4 * C, e, st));
     {   // x = conv_pos_embed(x) + x, modules.py:129-144 (causal, grouped, Mish)
         ConvDesc d;
@@ -463,53 +431,43 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
         FY_TRY(mf ? conv1d_bf16_mfma(d, f->pos2, (flags & FY_PRECISE) != 0, st) : conv1d_f32_direct(d, f->pos2, st));
     }
     const float* modbase = f->mod + (size_t)slot * c.depth * 6 * D;
+    bf16_t* const xn_lo = pr ? f->xn_lo : nullptr;
     for (int i = 0; i < c.depth; ++i) {
         const FlowBlockW& k = f->blk[i];
         const float* m = modbase + (size_t)i * 6 * D;       // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + D, m, f->xn, pr ? f->xn32 : nullptr, M, D);
+        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + D, m, f->xn, xn_lo, M, D);
         GemmEpi q;
-        q.bias = k.bqkv; q.out = pr ? (void*)f->qkv32 : (void*)f->qkv; q.out_bf16 = pr ? 0 : 1; q.ldc = 3 * inner;
+        q.bias = k.bqkv; q.out = f->qkv; q.out_bf16 = 1; q.ldc = 3 * inner;
         // x-transformers rotary embedding (head 0 of q and k only, modules.py:368-373) in the projection's epilogue, on the fp32
-        // sums before they are rounded to bf16
+        // sums before they are rounded to bf16 (or split into the two planes)
         q.rope = f->rope; q.rope_T = Tmax; q.rope_half = c.head_dim / 2; q.rope_stride = inner;
         if (pr) {
-            FY_TRY(gemm_f32a_precise(f->xn32, D, k.wqkv, M, 3 * inner, D, q, st));
-            {
-                // the score rows live in LDS: 16 (64 + Tmax) bytes per workgroup, above the 64 KB default from ~4000 frames on
-                const size_t at_lds = (size_t)4 * (64 + Tmax) * sizeof(float);
-                FY_CHECK(at_lds <= (size_t)160 * 1024, FY_ERR_ARG, "fy_flow (FY_PRECISE): %d frames exceed the fp32 attention's score buffer (10176 frames)", Tmax);
-                static size_t at_lds_set = 0;
-                if (at_lds > at_lds_set) {
-                    HIP_TRY(hipFuncSetAttribute((const void*)dit_attention_f32_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)at_lds));
-                    at_lds_set = at_lds;
-                }
-                hipLaunchKernelGGL(dit_attention_f32_k, dim3(cdiv(Tmax, 4), c.heads, nseq), dim3(256), at_lds, st,
-                                   f->qkv32, f->ao32, f->seq_len, Tmax, c.heads, streaming ? c.static_chunk : 0);
-                HIP_TRY(hipGetLastError());
-            }
+            q.a_lo = f->xn_lo; q.out_lo = f->qkv_lo;
+            FY_TRY(gemm_split(f->xn, D, k.wqkv, M, 3 * inner, D, q, st));
+            FY_TRY(dit_attention_split(f->qkv, f->qkv_lo, f->ao, f->ao_lo, f->seq_len, nseq, Tmax, c.heads, streaming ? c.static_chunk : 0, st));
         } else {
             FY_TRY(gemm_bf16(f->xn, D, k.wqkv, M, 3 * inner, D, q, st));
             FY_TRY(dit_attention(f->qkv, f->ao, f->seq_len, nseq, Tmax, c.heads, streaming ? c.static_chunk : 0, st));
         }
         GemmEpi o;
         o.mode = EPI_GATE_RESID; o.bias = k.bo; o.resid = f->h; o.gate = m + 2 * D; o.ldc = D;
-        if (pr) FY_TRY(gemm_f32a_precise(f->ao32, inner, k.wo, M, D, inner, o, st));
+        if (pr) { o.a_lo = f->ao_lo; FY_TRY(gemm_split(f->ao, inner, k.wo, M, D, inner, o, st)); }
         else FY_TRY(gemm_bf16(f->ao, inner, k.wo, M, D, inner, o, st));
-        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + 4 * D, m + 3 * D, f->xn, pr ? f->xn32 : nullptr, M, D);
+        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + 4 * D, m + 3 * D, f->xn, xn_lo, M, D);
         GemmEpi g;
-        g.bias = k.b1; g.act = ACT_GELU_TANH; g.out = pr ? (void*)f->ff32 : (void*)f->ff; g.out_bf16 = pr ? 0 : 1; g.ldc = FF;
-        if (pr) FY_TRY(gemm_f32a_precise(f->xn32, D, k.w1, M, FF, D, g, st));
+        g.bias = k.b1; g.act = ACT_GELU_TANH; g.out = f->ff; g.out_bf16 = 1; g.ldc = FF;
+        if (pr) { g.a_lo = f->xn_lo; g.out_lo = f->ff_lo; FY_TRY(gemm_split(f->xn, D, k.w1, M, FF, D, g, st)); }
         else FY_TRY(gemm_bf16(f->xn, D, k.w1, M, FF, D, g, st));
         GemmEpi r;
         r.mode = EPI_GATE_RESID; r.bias = k.b2; r.resid = f->h; r.gate = m + 5 * D; r.ldc = D;
-        if (pr) FY_TRY(gemm_f32a_precise(f->ff32, FF, k.w2, M, D, FF, r, st));
+        if (pr) { r.a_lo = f->ff_lo; FY_TRY(gemm_split(f->ff, FF, k.w2, M, D, FF, r, st)); }
         else FY_TRY(gemm_bf16(f->ff, FF, k.w2, M, D, FF, r, st));
     }
     const float* fn = f->fin + (size_t)slot * 2 * D;            // (scale, shift), modules.py:261
-    hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, fn, fn + D, f->xn, pr ? f->xn32 : nullptr, M, D);
+    hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, fn, fn + D, f->xn, xn_lo, M, D);
     GemmEpi p;
     p.bias = f->b_out; p.out = f->v; p.out_bf16 = 0; p.ldc = C;
-    if (pr) FY_TRY(gemm_f32a_precise(f->xn32, D, f->w_out, M, C, D, p, st));
+    if (pr) { p.a_lo = f->xn_lo; FY_TRY(gemm_split(f->xn, D, f->w_out, M, C, D, p, st)); }
     else FY_TRY(gemm_bf16(f->xn, D, f->w_out, M, C, D, p, st));
     HIP_TRY(hipGetLastError());
     return FY_OK;
@@ -570,7 +528,7 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
     if (flags & FY_PRECISE) FY_TRY(ensure_precise(f));
     for (int step = 0; step < c.n_timesteps; ++step) {
         hipLaunchKernelGGL(dit_assemble_k, dim3(Tmax, 2 * B), dim3(4 * C), 0, st, f->x, f->cond, f->mu, f->spks, d_T, f->a_in,
-                           (flags & FY_PRECISE) ? f->a_in32 : nullptr, Tmax, C);
+                           (flags & FY_PRECISE) ? f->a_in_lo : nullptr, Tmax, C);
         FY_TRY(dit_forward(f, 2 * B, Tmax, step, (flags & FY_STREAMING) != 0, flags, st));
         hipLaunchKernelGGL(euler_k, dim3(Tmax, B), dim3(128), 0, st, f->x, f->v, d_T, Tmax, C, f->dt_of_step[step], c.cfg_rate);
     }
@@ -644,7 +602,7 @@ extern "C" int fy_dit_estimator(fy_flow* f, float* x, const float* mask, const f
         for (int s = 0; s < B2; ++s) {
             hipLaunchKernelGGL(dit_assemble_k, dim3(T, 1), dim3(4 * C), 0, st, sx + (size_t)s * T * C, sc + (size_t)s * T * C,
                                sm + (size_t)s * T * C, spks + (size_t)s * C, f->seq_len + s, f->a_in + (size_t)s * T * 4 * C,
-                               (flags & FY_PRECISE) ? f->a_in32 + (size_t)s * T * 4 * C : nullptr, T, C);
+                               (flags & FY_PRECISE) ? f->a_in_lo + (size_t)s * T * 4 * C : nullptr, T, C);
         }
     }
     // a_in was written by rows of T (not f->Tmax): run the estimator with Tmax = T; h is overwritten only after a_in is complete

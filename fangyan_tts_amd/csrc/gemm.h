@@ -24,6 +24,11 @@ struct GemmEpi {
     // [rope_stride, rope_stride + 2*rope_half) at position (row % rope_T), table [rope_T][rope_half] of (cos, sin)
     const float2* rope = nullptr;
     int rope_T = 0, rope_half = 0, rope_stride = 0;
+    // split-operand (fp32-class) products, gemm_split: the A operand arrives as TWO bf16 planes, x = hi + lo with hi = bf16(x) and
+    // lo = bf16(x - hi) - a_lo is the lo plane ([M][lda] like A); out_lo != null stores the result the same way (out = hi plane,
+    // out_lo = lo plane, both bf16 [M][ldc]) for the next product, after the exact-tanh GELU (act) or the rotary embedding (rope)
+    const bf16_t* a_lo = nullptr;
+    void* out_lo = nullptr;
 #ifdef FY_GEMM_STAMPS
     int stamp_slot = 0;                // tests/micro/gemm_stamps.hip: which 4096-workgroup slot of the stamp buffer this launch writes
 #endif
@@ -37,6 +42,11 @@ extern int gemm_tile_override;     // microbenchmarks only: 0 = automatic choice
 int gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st);
 // A: fp32 [M][lda], split into bf16 hi + lo on the fly (fp32-class accuracy when W is bf16-exact)
 int gemm_f32a_precise(const float* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st);
+
+// A = A_hi + epi.a_lo, two bf16 planes [M][lda] written by the producer (16 mantissa bits): two MFMAs per fragment into one fp32
+// accumulator on the LDS-DMA ring kernel - the fp32-class (FY_PRECISE) flow decoder at 2x the MFMA work of gemm_bf16, not the
+// register-staged fp32 path's 5x.  Outputs: fp32 store, gated residual, or split bf16 planes (epi.out_lo).
+int gemm_split(const bf16_t* A_hi, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st);
 
 // A: fp32 [M][lda], split EXACTLY into bf16 hi + mid + lo (3 MFMAs per fragment): with bf16-exact W every product is exact and
 // the accumulation is fp32 - the LM prefill over many rows (same fidelity as gemv_bf16w, whose 8-row form re-streams the weights)

@@ -130,7 +130,8 @@ template <int PRECISE, int EPI, int BM>
 __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ Av, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
     extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
     constexpr int NT = BM * 2;                               // threads: (BM/64) x 2 waves, each a 64x64 tile
-    constexpr int A_ELEMS = (PRECISE ? PRECISE : 1) * BM * GM_PITCH, B_ELEMS = GM_BN * GM_PITCH, BUF = A_ELEMS + B_ELEMS;
+    constexpr int PL = PRECISE == 4 ? 2 : (PRECISE ? PRECISE : 1);      // planes of the A operand in LDS (4: hi + lo arrive as two bf16 planes)
+    constexpr int A_ELEMS = PL * BM * GM_PITCH, B_ELEMS = GM_BN * GM_PITCH, BUF = A_ELEMS + B_ELEMS;
     constexpr int A_LOADS = BM * 8 / NT, B_LOADS = GM_BN * 8 / NT;      // 16-B chunks per thread per tile
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1, lr = lane & 31, kh = lane >> 5;
@@ -150,7 +151,10 @@ __global__ __launch_bounds__(BM * 2) void gemm_bf16_k(const void* __restrict__ A
         for (int i = 0; i < A_LOADS; ++i) {
             int idx = tid + i * NT, row = idx >> 3, kc = (idx & 7) * 8;
             int gm = m0 + row;
-            if (PRECISE) {
+            if (PRECISE == 4) {
+                ra[i] = gm < M ? *reinterpret_cast<const uint4*>(Ab + (long)gm * lda + k0 + kc) : make_uint4(0, 0, 0, 0);
+                ral[i] = gm < M ? *reinterpret_cast<const uint4*>(e.a_lo + (long)gm * lda + k0 + kc) : make_uint4(0, 0, 0, 0);
+            } else if (PRECISE) {
                 float4 x0 = make_float4(0, 0, 0, 0), x1 = x0;
                 if (gm < M) {
                     const float* p = Af + (long)gm * lda + k0 + kc;
@@ -263,16 +267,20 @@ void gemm_set_stamps(unsigned long long* p) { hipMemcpyToSymbol(HIP_SYMBOL(gemm_
 // STAG: the two wave groups of a one-per-CU workgroup run half a K step apart (comment at the loop).  MF = 1: the products on
 // v_mfma_f32_16x16x32_bf16 instead of 32x32x16 - the same cycles per flop, the same bits out, but the chip holds a higher clock
 // on it (MI355X_MICROARCH.md, DVFS give-back item 7): 5-19 % less time at two or more workgroups per CU.
-template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0>
+// SP = 1: the split-operand form (gemm_split): the stage holds TWO A tiles, the hi and the lo plane of x = hi + lo, and every
+// fragment pair meets its B fragment in two MFMAs that accumulate into the same registers (MF = 1 only).
+template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0, int SP = 0>
 __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
     extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
     char* smem = reinterpret_cast<char*>(gm_smem);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NWAVE = BM == 128 ? 4 : 8;                             // BM 128 (with BN 128): 2 x 2 waves of 64x64, 48 KB ring, three workgroups per CU
     constexpr int WN = BN / 64, WM = NWAVE / WN, MI = BM / WM / 32;       // waves along N / M, 32-row tiles per wave
-    constexpr int STAGE = (BM + BN) * G2_BK * 2, STAGES = 3, NB = BN / (NWAVE * 16);   // NB: B DMAs per wave and stage
-    constexpr int NA_ALL = BM / 16, NA = (NA_ALL + NWAVE - 1) / NWAVE, NA_LAST = NA_ALL - (NA - 1) * NWAVE;   // A DMAs: wave-instruction j = i * NWAVE + wid fills rows [16 j, 16 j + 16); the last round only on waves < NA_LAST
-    constexpr int BOFF = BM * G2_BK * 2;                                  // the B tile follows the A tile inside a stage
+    static_assert(!SP || (MF && !STAG), "the split-operand form exists for the 16x16x32 products without staggered wave groups");
+    constexpr int APL = SP ? 2 : 1;                                       // A planes per stage
+    constexpr int STAGE = (APL * BM + BN) * G2_BK * 2, STAGES = 3, NB = BN / (NWAVE * 16);   // NB: B DMAs per wave and stage
+    constexpr int NA_ALL = APL * BM / 16, NA = (NA_ALL + NWAVE - 1) / NWAVE, NA_LAST = NA_ALL - (NA - 1) * NWAVE;   // A DMAs: wave-instruction j = i * NWAVE + wid fills rows [16 j, 16 j + 16) (SP: of plane j / (BM / 16)); the last round only on waves < NA_LAST
+    constexpr int BOFF = APL * BM * G2_BK * 2;                            // the B tile follows the A tile(s) inside a stage
     const int wm = wid / WN, wn = wid % WN, lr = lane & 31, kh = lane >> 5;
     // XCD-aware tile order (see gemm_bf16_k)
     const int ntn = N / BN, nwg = gridDim.x;
@@ -288,8 +296,10 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     const bool a_last = NA_LAST == NWAVE || wid < NA_LAST;           // wave-uniform: this wave takes part in the last round of A DMAs
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int row = (i * NWAVE + wid) * 16 + (lane >> 2), c = (lane & 3) ^ G2_SW(row);
-        a_src[i] = A + (long)min(m0 + row, M - 1) * lda + c * 8;
+        const int j = i * NWAVE + wid;
+        const int row = (SP ? j % (BM / 16) : j) * 16 + (lane >> 2), c = (lane & 3) ^ G2_SW(row);
+        const bf16_t* Ap = (SP && j >= BM / 16) ? e.a_lo : A;          // wave-uniform
+        a_src[i] = Ap + (long)min(m0 + row, M - 1) * lda + c * 8;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -434,15 +444,27 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
         const char* sb = smem + (t % STAGES) * STAGE;
         frag_ab fa[2][MI], fb[2][2];
         if constexpr (MF) {
+            frag_ab fl[SP ? 2 : 1][SP ? MI : 1];
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j >> 1][j & 1] = *reinterpret_cast<const frag_ab*>(sb + b16[j]);
 #pragma unroll
             for (int i = 0; i < 2 * MI; ++i) fa[i & 1][i >> 1] = *reinterpret_cast<const frag_ab*>(sb + a16[i]);
+            if constexpr (SP) {
+#pragma unroll
+                for (int i = 0; i < 2 * MI; ++i) fl[i & 1][i >> 1] = *reinterpret_cast<const frag_ab*>(sb + a16[i] + BM * G2_BK * 2);
+            }
 #pragma unroll
             for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i & 1][i >> 1], fb[j >> 1][j & 1], acc4[i][j], 0, 0, 0);
+            if constexpr (SP) {
+#pragma unroll
+                for (int i = 0; i < 2 * MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[i & 1][i >> 1], fb[j >> 1][j & 1], acc4[i][j], 0, 0, 0);
+            }
             continue;
         }
         auto load_frags = [&](int ks, frag_ab (&a)[MI], frag_ab (&b)[2]) {
@@ -476,8 +498,9 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     // a 32-row block's eight table rows in one batch, one block AHEAD of their use (under the previous block's stores) - fetched
     // where they are used, each row's 16 bytes cost a trip to L2 in the middle of the store loop (qkv at M = 6400: +11 us on the
     // 320x256 tile, whose epilogue nothing hides).
+    constexpr bool RE = EPI == 0 || EPI == 4;                       // epilogues that may carry the rotary embedding
     int rope_col = -1;                                              // float2 index of this lane's first pair inside a table row
-    if (EPI == 0 && e.rope) {
+    if (RE && e.rope) {
         const int nn = n >= e.rope_stride ? n - e.rope_stride : n;
         if (n < 2 * e.rope_stride && nn < 2 * e.rope_half) rope_col = nn >> 1;
     }
@@ -490,10 +513,10 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
         for (int it = 0; it < 8; ++it)
             t[it] = *reinterpret_cast<const float4*>(e.rope + (long)(min(m00 + it * 4, M - 1) % e.rope_T) * e.rope_half + rope_col);
     };
-    if (EPI == 0 && RAHEAD) rope_fetch(0, rt);
+    if (RE && RAHEAD) rope_fetch(0, rt);
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        if (EPI == 0 && !RAHEAD) rope_fetch(mi, rt);             // before the block's trip through LDS
+        if (RE && !RAHEAD) rope_fetch(mi, rt);                   // before the block's trip through LDS
         if constexpr (MF) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -520,7 +543,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
 #pragma unroll
         for (int it = 0; it < 8; ++it) vr[it] = make_float4(vq[it][0], vq[it][1], vq[it][2], vq[it][3]);
         __builtin_amdgcn_wave_barrier();                         // the next quarter overwrites the park region
-        if constexpr (EPI == 0 && RAHEAD) { if (mi + 1 < MI) rope_fetch(mi + 1, rn); }     // travels under this block's stores
+        if constexpr (RE && RAHEAD) { if (mi + 1 < MI) rope_fetch(mi + 1, rn); }     // travels under this block's stores
         const int mb = m0 + wm * (MI * 32) + mi * 32 + rsub;
         float4 old[8];
         if (EPI == 3) {
@@ -542,6 +565,24 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
                 *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + n) = o;
             } else if (EPI == 2) {
                 *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
+            } else if (EPI == 4 || EPI == 5) {
+                // fp32-class result for the next split-operand product: exact-tanh GELU (5) or the rotary embedding (4) on the fp32
+                // sums, then x = hi + lo as two bf16 planes
+                if (EPI == 5) { v.x = act_gelu_tanh(v.x); v.y = act_gelu_tanh(v.y); v.z = act_gelu_tanh(v.z); v.w = act_gelu_tanh(v.w); }
+                if (EPI == 4 && rope_col >= 0) {
+                    const float4 t = rt[it];
+                    const float a = v.x, b = v.y, c = v.z, d = v.w;
+                    v.x = a * t.x - b * t.y; v.y = b * t.x + a * t.y;
+                    v.z = c * t.z - d * t.w; v.w = d * t.z + c * t.w;
+                }
+                const bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
+                uint2 ph, pl;
+                ph.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                ph.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+                pl.x = (uint32_t)f32_to_bf16(v.x - bf16_to_f32(h0)) | ((uint32_t)f32_to_bf16(v.y - bf16_to_f32(h1)) << 16);
+                pl.y = (uint32_t)f32_to_bf16(v.z - bf16_to_f32(h2)) | ((uint32_t)f32_to_bf16(v.w - bf16_to_f32(h3)) << 16);
+                *reinterpret_cast<uint2*>((bf16_t*)e.out + (long)m * e.ldc + n) = ph;
+                *reinterpret_cast<uint2*>((bf16_t*)e.out_lo + (long)m * e.ldc + n) = pl;
             } else {
                 if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
                 if (EPI == 0 && rope_col >= 0) {                 // x-transformers apply_rotary_pos_emb on two interleaved pairs (epi_rope's arithmetic)
@@ -556,7 +597,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
                 *reinterpret_cast<uint2*>((bf16_t*)e.out + (long)m * e.ldc + n) = pk;
             }
         }
-        if constexpr (EPI == 0 && RAHEAD) {
+        if constexpr (RE && RAHEAD) {
             if (rope_col >= 0) {
 #pragma unroll
                 for (int it = 0; it < 8; ++it) rt[it] = rn[it];
@@ -566,16 +607,16 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     G2_STAMP(3);
 }
 
-template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0>
+template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0, int SP = 0>
 static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = (size_t)3 * (BM + BN) * G2_BK * 2;          // 256x256: 96 KB; 320x256: 108 KB (one workgroup per CU); 256x128: 72 KB (two); 128x128: 48 KB (three)
+    const size_t lds = (size_t)3 * ((SP ? 2 : 1) * BM + BN) * G2_BK * 2;          // 256x256: 96 KB; 320x256: 108 KB (one workgroup per CU); 256x128: 72 KB (two); 128x128: 48 KB (three); split operand: 256x128 120 KB (one), 128x128 72 KB (two)
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN, BM, STAG, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN, BM, STAG, MF, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
     dim3 grid((N / BN) * cdiv(M, BM));
-    hipLaunchKernelGGL((gemm256_k<EPI, BN, BM, STAG, MF>), grid, dim3(BM == 128 ? 256 : 512), lds, st, A, lda, W, M, N, K, epi);
+    hipLaunchKernelGGL((gemm256_k<EPI, BN, BM, STAG, MF, SP>), grid, dim3(BM == 128 ? 256 : 512), lds, st, A, lda, W, M, N, K, epi);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -583,7 +624,7 @@ static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int
 template <int PRECISE, int EPI, int BM>
 static int gemm_launch3(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = (size_t)2 * ((PRECISE ? PRECISE : 1) * BM + GM_BN) * GM_PITCH * sizeof(bf16_t);
+    const size_t lds = (size_t)2 * ((PRECISE == 4 ? 2 : (PRECISE ? PRECISE : 1)) * BM + GM_BN) * GM_PITCH * sizeof(bf16_t);
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_k<PRECISE, EPI, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -669,6 +710,31 @@ int gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, co
 int gemm_f32a_precise(const float* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     FY_TRY(gemm_check(A, lda, W, M, N, K, epi, 4));
     return gemm_launch<2>(A, lda, W, M, N, K, epi, st);
+}
+
+// x = hi + lo as two bf16 planes (gemm.h): the ring kernel with two A tiles per stage; the register-staged kernel for N % 128 != 0
+template <int EPI>
+static int gemm_split_launch(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
+    if (N % 128 == 0 && K % G2_BK == 0) {
+        static const int tile = getenv("FY_GEMM_SPLIT_TILE") ? atoi(getenv("FY_GEMM_SPLIT_TILE")) : 0;   // experiments: 256 = 256x128 tiles, one workgroup per CU
+        if (tile == 256) return gemm_launch_256<EPI, 128, 256, 0, 1, 1>(A, lda, W, M, N, K, epi, st);
+        return gemm_launch_256<EPI, 128, 128, 0, 1, 1>(A, lda, W, M, N, K, epi, st);
+    }
+    if constexpr (EPI == 2 || EPI == 3) return gemm_launch3<4, EPI, 128>(A, lda, W, M, N, K, epi, st);
+    FY_CHECK(false, FY_ERR_ARG, "gemm_split: a split-plane output needs N %% 128 == 0 and K %% 32 == 0 (N %d, K %d)", N, K);
+}
+
+int gemm_split(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
+    FY_TRY(gemm_check(A, lda, W, M, N, K, epi, 2));
+    FY_CHECK(epi.a_lo && ((uintptr_t)epi.a_lo & 15) == 0, FY_ERR_ARG, "gemm_split: the lo plane of A is missing or misaligned");
+    ProfScope prof("gemm_split", 4.0 * M * N * K, st);
+    if (epi.mode == EPI_GATE_RESID) return gemm_split_launch<3>(A, lda, W, M, N, K, epi, st);
+    if (epi.out_lo) {
+        FY_CHECK(epi.act == ACT_NONE || (epi.act == ACT_GELU_TANH && !epi.rope), FY_ERR_ARG, "gemm_split: only GELU(tanh) or the rotary embedding is fused");
+        return epi.act == ACT_GELU_TANH ? gemm_split_launch<5>(A, lda, W, M, N, K, epi, st) : gemm_split_launch<4>(A, lda, W, M, N, K, epi, st);
+    }
+    FY_CHECK(!epi.out_bf16 && epi.act == ACT_NONE && !epi.rope, FY_ERR_ARG, "gemm_split: outputs are fp32, the gated residual, or split bf16 planes");
+    return gemm_split_launch<2>(A, lda, W, M, N, K, epi, st);
 }
 
 int gemm_f32a_exact(const float* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
