@@ -218,7 +218,11 @@ def test_tts_speed(tiny):
     assert eng.speed(mel.to(DEV), 1.3).shape[2] == int(41 / 1.3)
 
 
-def test_attention_workgroup_forms_agree(full, tmp_path):
+@pytest.mark.parametrize("T,lens,other_form", [
+    (300, [300, 287, 150, 300, 33, 300, 256, 1], "4"),          # one 10-wave workgroup per (sequence, head) against the 4-wave form
+    (512, [512, 449, 448, 512, 65, 512, 500, 1], "4"),          # 16 waves
+])
+def test_attention_workgroup_forms_agree(T, lens, other_form, tmp_path):
     """dit_attention picks one workgroup per (sequence, head) when those cover the chip (batch >= 4 at full size) and 4-wave
     workgroups otherwise; both walk a query's key tiles in the same order, so the estimator's output must be identical bit for
     bit - checked on ragged lengths (dead waves, the masked last tile), plain and with the chunk mask, the other form forced
@@ -226,12 +230,11 @@ def test_attention_workgroup_forms_agree(full, tmp_path):
     import os
     import subprocess
     import sys
-    eng, _, _ = full
-    T, B2 = 300, 8
+    eng, _, _ = make(FlowCfg(), max_batch=4, max_frames=T)
+    B2 = 8
     g = lambda name, shape: torch.from_numpy(synth.normal(f"in.attnforms.{name}", shape))
     x, mu, cond, spks = g("x", (B2, 80, T)), g("mu", (B2, 80, T)), g("cond", (B2, 80, T)), g("spks", (B2, 80))
     t = torch.full((B2,), 0.3)
-    lens = [300, 287, 150, 300, 33, 300, 256, 1]
     mask = torch.zeros(B2, 1, T)
     for b, n in enumerate(lens):
         mask[b, 0, :n] = 1
@@ -242,14 +245,14 @@ import numpy as np, torch, sys
 sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
 import test_flow_gpu as tf
 from fangyan_tts_amd.spec import FlowCfg
-eng, _, _ = tf.make(FlowCfg())
+eng, _, _ = tf.make(FlowCfg(), max_batch=4, max_frames={T})
 z = np.load({str(tmp_path / 'in.npz')!r})
 d = lambda k: torch.from_numpy(z[k]).to(tf.DEV)
 out = [eng.estimator(d('x'), d('mask'), d('mu'), d('t'), d('spks'), d('cond'), streaming=s).cpu().numpy() for s in (False, True)]
 np.savez({str(tmp_path / 'out.npz')!r}, plain=out[0], stream=out[1])
 """
     np.savez(tmp_path / "in.npz", x=x.numpy(), mask=mask.numpy(), mu=mu.numpy(), t=t.numpy(), spks=spks.numpy(), cond=cond.numpy())
-    env = dict(os.environ, FY_ATTN_WAVES="4", PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
+    env = dict(os.environ, FY_ATTN_WAVES=other_form, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     other = np.load(tmp_path / "out.npz")
