@@ -596,9 +596,137 @@ __global__ __launch_bounds__(256) void llm_attention_step_k(const float* __restr
     }
 }
 
+// The same step with ONE block per (row, kv head) serving all Hq / Hk query heads of the group (<= 8): the group's cached keys
+// are read once (a thread per position: its 64-dim dot product against every head's rotated query out of LDS), the values are
+// staged through LDS in chunks of GQ_CH positions (one coalesced burst) and every head's wave walks them there.  R x Hk blocks
+// where the per-head kernel above launches R x Hq - beside the flow decoder an LM block displaces a GEMM workgroup from its CU for
+// as long as it lives, and this kernel's 448 blocks x 6 us per layer were a third of the LM's block-seconds.
+#define GQ_CH 128
+__global__ __launch_bounds__(512) void llm_attention_step_gqa_k(const float* __restrict__ qkv, float* __restrict__ Kc, float* __restrict__ Vc,
+                                                                const int* __restrict__ row_seq, const int* __restrict__ row_pos,
+                                                                const float* __restrict__ inv_freq, float* __restrict__ out, int o_ld,
+                                                                int Hq, int Hk, int max_ctx, float scale, bf16_t* __restrict__ img) {
+    extern __shared__ float sh[];
+    float* qs = sh;                               // [8][64] rotated queries of the group
+    float* knew = sh + 512;                       // [64] this step's rotated key, [64] its value
+    float* vnew = sh + 576;
+    float* sc = sh + 640;                         // [grp][max_ctx] scores, then probabilities
+    const int r = blockIdx.x, hk = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int grp = Hq / Hk;
+    float* vbuf = sc + ((grp * max_ctx + 3) & ~3);   // [GQ_CH][64] staged values (16-byte aligned)
+    bf16_t* psb = reinterpret_cast<bf16_t*>(vbuf + GQ_CH * 64);       // [8 waves][192] split scratch of the image writer
+    const int seq = row_seq[r], pos = row_pos[r];
+    const int ld = (Hq + 2 * Hk) * 64;
+    const float* row = qkv + (long)r * ld;
+    const float ang = (float)pos * inv_freq[lane & 31];
+    float sn, cs;
+    sincosf(ang, &sn, &cs);
+    float* Kb = Kc + ((long)seq * Hk + hk) * max_ctx * 64;
+    float* Vb = Vc + ((long)seq * Hk + hk) * max_ctx * 64;
+    if (wid < grp) {
+        const float qv = row[(hk * grp + wid) * 64 + lane];
+        const float qo = __shfl_xor(qv, 32, 64);
+        qs[wid * 64 + lane] = lane < 32 ? qv * cs - qo * sn : qv * cs + qo * sn;
+    }
+    if (wid == 0) {
+        const float kv = row[(Hq + hk) * 64 + lane], vv = row[(Hq + Hk + hk) * 64 + lane];
+        const float ko = __shfl_xor(kv, 32, 64);
+        const float kr = lane < 32 ? kv * cs - ko * sn : kv * cs + ko * sn;
+        Kb[(long)pos * 64 + lane] = kr;
+        Vb[(long)pos * 64 + lane] = vv;
+        knew[lane] = kr;
+        vnew[lane] = vv;
+    }
+    __syncthreads();
+    // scores of the cached positions: one position per thread, its key row against every head's query (the per-head kernel's order
+    // of the 64 products)
+    for (int j = tid; j < pos; j += 512) {
+        const float4* kp = reinterpret_cast<const float4*>(Kb + (long)j * 64);
+        float4 k4[16];
+#pragma unroll
+        for (int d4 = 0; d4 < 16; ++d4) k4[d4] = kp[d4];
+        for (int h = 0; h < grp; ++h) {
+            const float* q = qs + h * 64;
+            float s = 0.f;
+#pragma unroll
+            for (int d4 = 0; d4 < 16; ++d4) {
+                s = fmaf(q[d4 * 4 + 0], k4[d4].x, s);
+                s = fmaf(q[d4 * 4 + 1], k4[d4].y, s);
+                s = fmaf(q[d4 * 4 + 2], k4[d4].z, s);
+                s = fmaf(q[d4 * 4 + 3], k4[d4].w, s);
+            }
+            sc[h * max_ctx + j] = s * scale;
+        }
+    }
+    __syncthreads();
+    // softmax: wave h owns head h
+    float p_new = 0.f, sum = 1.f;
+    if (wid < grp) {
+        float* sch = sc + wid * max_ctx;
+        const float s_new = wave_sum(qs[wid * 64 + lane] * knew[lane]) * scale;
+        float mx = s_new;
+        for (int j = lane; j < pos; j += 64) mx = fmaxf(mx, sch[j]);
+        mx = wave_max(mx);
+        float su = 0.f;
+        for (int j = lane; j < pos; j += 64) {
+            const float p = expf(sch[j] - mx);
+            sch[j] = p;
+            su += p;
+        }
+        p_new = expf(s_new - mx);
+        sum = wave_sum(su) + p_new;
+    }
+    // values: GQ_CH positions at a time through LDS; thread (head = wave, dim = lane) accumulates in position order
+    float acc = 0.f;
+    for (int c0 = 0; c0 < pos; c0 += GQ_CH) {
+        const int n = min(GQ_CH, pos - c0);
+        __syncthreads();                                  // the probabilities are written / the previous chunk has been read
+        const float4* vsrc = reinterpret_cast<const float4*>(Vb + (long)c0 * 64);
+        float4 v4[GQ_CH * 16 / 512];
+#pragma unroll
+        for (int i = 0; i < GQ_CH * 16 / 512; ++i) {
+            const int e = tid + i * 512;
+            v4[i] = e < n * 16 ? vsrc[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < GQ_CH * 16 / 512; ++i) reinterpret_cast<float4*>(vbuf)[tid + i * 512] = v4[i];
+        __syncthreads();
+        if (wid < grp) {
+            const float* sch = sc + wid * max_ctx + c0;
+            for (int j = 0; j < n; ++j) acc = fmaf(sch[j], vbuf[j * 64 + lane], acc);
+        }
+    }
+    if (wid >= grp) return;
+    const int hq = hk * grp + wid;
+    const float o = (acc + p_new * vnew[lane]) / sum;
+    if (!img) { out[(long)r * o_ld + hq * 64 + lane] = o; return; }
+    unsigned h, m, l;
+    gv32_split3(o, h, m, l);
+    bf16_t* ps = psb + wid * 192;
+    ps[lane] = (bf16_t)h; ps[64 + lane] = (bf16_t)m; ps[128 + lane] = (bf16_t)l;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane < 24) {
+        const int plane = lane >> 3, pc = lane & 7, col0 = hq * 64 + 8 * pc;
+        const uint4 piece = *reinterpret_cast<const uint4*>(ps + plane * 64 + pc * 8);
+        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(img) + gv32_off(Hq * 4, r, col0, plane)) = piece;
+    }
+}
+
 int llm_attention_step(const float* qkv, float* Kc, float* Vc, const int* row_seq, const int* row_pos, const float* inv_freq,
                        float* out, int o_ld, int R, int Hq, int Hk, int max_ctx, hipStream_t st, bf16_t* img) {
     FY_CHECK(qkv && Kc && Vc && row_seq && row_pos && inv_freq && (out || img) && R >= 1 && Hq % Hk == 0, FY_ERR_ARG, "llm_attention_step: bad arguments");
+    {
+        // one block per (row, kv head) when the group fits a block's waves (FY_LLM_ATTN_GQA=0: the per-head kernel)
+        static const int gqa = getenv("FY_LLM_ATTN_GQA") ? atoi(getenv("FY_LLM_ATTN_GQA")) : 1;
+        const int grp = Hq / Hk;
+        const size_t lds_g = (640 + (((size_t)grp * max_ctx + 3) & ~(size_t)3) + GQ_CH * 64) * sizeof(float) + 8 * 192 * sizeof(bf16_t);
+        if (gqa && grp <= 8 && lds_g <= 64 * 1024) {
+            hipLaunchKernelGGL(llm_attention_step_gqa_k, dim3(R, Hk), dim3(512), lds_g, st, qkv, Kc, Vc, row_seq, row_pos, inv_freq, out, o_ld, Hq, Hk,
+                               max_ctx, 0.125f, img);
+            HIP_TRY(hipGetLastError());
+            return FY_OK;
+        }
+    }
     size_t lds = (64 + (size_t)max_ctx + 256 + 8) * sizeof(float);
     FY_CHECK(lds <= 64 * 1024, FY_ERR_ARG, "llm_attention_step: context %d too long for the score buffer", max_ctx);
     hipLaunchKernelGGL(llm_attention_step_k, dim3(R, Hq), dim3(256), lds, st, qkv, Kc, Vc, row_seq, row_pos, inv_freq, out, o_ld, Hq, Hk,
