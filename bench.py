@@ -178,7 +178,7 @@ def dit_roofline(ms, flops, n, where, traffic):
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {"bound": "mfma", "kernel": "DiT linears: gemm256_k (LDS-DMA ring; per shape 320x256 tiles with staggered wave groups, 256x128 or 128x128 tiles on 16x16x32 MFMAs)",
             "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "HBM-side bytes per launch, mean over every gemm256_k launch of the run (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over bench.py itself, separate passes: profiles/r03_bench_pmc.json)",
+            "traffic_unit": "HBM-side bytes per launch, mean over every gemm256_k launch of the run (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over bench.py itself, separate passes: profiles/r04_bench_pmc.json)",
             "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2), "gflop_per_launch": round(flops / max(n, 1) / 1e9, 3), "measured_over": where}
 
 
@@ -524,7 +524,10 @@ def main():
         L.fy_prof_reset()
         return r
     ms_t, flops_t, n_t = events_pass("gemm_bf16")
-    ms_vt, bytes_vt, n_vt = events_pass("gemv")
+    # the LM's launches in the timed configuration: the few-CU persistent 32-row step (one launch per token step) when the pipeline decodes
+    # 9 .. 32 sequences per call, else the per-operation products
+    lm32 = pipelined and BATCH * group > 8 and os.environ.get("FY_PIPE_LM_PERSISTENT32", "1") != "0" and os.environ.get("FY_LLM_PERSISTENT32", "1") != "0"
+    ms_vt, bytes_vt, n_vt = events_pass("llm_decode32" if lm32 else "gemv")
 
     # ---- one batch alone (no pipelining): what tts_batch takes, LM on the persistent one-launch token step
     torch.cuda.synchronize()
@@ -537,42 +540,55 @@ def main():
 
     where_t = (f"HIP events on the launch stream around every launch, over a repeat of the {a.steps} timed steps in the timed configuration "
                f"(pipelined: {pipelined})")
-    roofline = dit_roofline(ms_t, flops_t, n_t, where_t, _pmc("r03_bench_pmc.json", "kernels", "gemm256_k", "traffic_bytes"))
-    roofline["why_this_kernel"] = ("the kernel family with the largest share of GPU time in the timed region (profiles/r03_bench_kernel_stats.csv); "
+    roofline = dit_roofline(ms_t, flops_t, n_t, where_t, _pmc("r04_bench_pmc.json", "kernels", "gemm256_k", "traffic_bytes"))
+    roofline["why_this_kernel"] = ("the kernel family with the largest share of GPU time in the timed region (profiles/r04_bench_kernel_stats.csv); "
                                    "bound MFMA: 2 M N K flop per launch, SURVEY 8(d)")
     roofline["one_step_alone"] = dit_roofline(ms, flops, n, "the same events over one un-pipelined step (nothing else on the GPU)", None)
     roofline["stage_ms_per_step_alone"] = {k: round(v[0], 3) for k, v in prof.items()}
 
-    # ---- the LM's decode products (second by GPU time): HBM-bound by SURVEY 8(d) - every bf16 weight is streamed once per token
-    # step, now for 32 rows (4 steps' batches) per pass.  algorithmic bytes = the weights of each product.
+    # ---- the LM's decode (second by GPU time): HBM-bound by SURVEY 8(d) - every bf16 weight is streamed once per token step, for 32 rows
+    # (4 steps' batches) per pass.  algorithmic bytes = the weights (727.8 MB per token step).  Measured in the timed configuration
+    # (events over the repeat of the timed steps, above) and alone, for both forms: the few-CU persistent step (what the pipeline
+    # runs since round 4) and the per-operation products of round 3.
     text = [d["text"].reshape(-1).tolist() for d in inputs]
     ptext = [d["prompt_text"].reshape(-1).tolist() for d in inputs]
     G = group
     eng = model.llms[0]
     was = eng.persistent
-    eng.set_decode_mode(False)
-    eng.generate(text * G, ptext * G, [[] for _ in range(BATCH * G)], min_len=forced * G, max_len=forced * G)
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    eng.generate(text * G, ptext * G, [[] for _ in range(BATCH * G)], min_len=forced * G, max_len=forced * G)
-    torch.cuda.synchronize()
-    lm_ms = 1e3 * (time.perf_counter() - t2)
-    pv = _stage_profile(L, _lib, lambda: eng.generate(text * G, ptext * G, [[] for _ in range(BATCH * G)], min_len=forced * G, max_len=forced * G), names=("gemv",))
-    ms_v, bytes_v, n_v = pv["gemv"]
-    eng.set_decode_mode(was)
     step_bytes = 727810048
+
+    def lm_alone(persistent, name):
+        eng.set_decode_mode(persistent)
+        gen = lambda: eng.generate(text * G, ptext * G, [[] for _ in range(BATCH * G)], min_len=forced * G, max_len=forced * G)
+        gen()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        gen()
+        torch.cuda.synchronize()
+        ms_call = 1e3 * (time.perf_counter() - t2)
+        ms_k, bytes_k, n_k = _stage_profile(L, _lib, gen, names=(name,))[name]
+        gbps = bytes_k / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
+        return {"achieved": round(gbps, 1), "frac": round(gbps / PEAK_HBM_GBPS, 4), "avg_launch_us": round(1e3 * ms_k / max(n_k, 1), 2), "launches": n_k,
+                "generate_ms": round(ms_call, 2), "rows": BATCH * G, "ms_per_token_step": round(ms_call / N_TOK, 4),
+                "weight_GBps_at_token_step_level": round(step_bytes / (ms_call / N_TOK * 1e-3) / 1e9, 1)}
+    alone32 = lm_alone(True, "llm_decode32") if BATCH * G > 8 else None
+    alone_ops = lm_alone(False, "gemv")
+    eng.set_decode_mode(was)
     gb_t = bytes_vt / (ms_vt * 1e-3) / 1e9 if ms_vt > 0 else 0.0
-    gb_a = bytes_v / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0
-    roofline_lm = {"bound": "hbm", "kernel": f"LM decode products at {BATCH * G} rows per weight pass: gemv32_k (qkv, o-proj, gate/up, down of 24 layers + llm_decoder; 97 launches per token step)",
+    if lm32:
+        kname = (f"llm_decode32_k: ONE persistent launch per token step for {BATCH * G} sequences on 76 workgroups / CUs (24 layers + llm_decoder, weights "
+                 "HBM -> registers a tile ahead, operands as A images in registers, 120 grid-wide hand-offs)")
+    else:
+        kname = f"LM decode products at {BATCH * G} rows per weight pass: gemv32_k (qkv, o-proj, gate/up, down of 24 layers + llm_decoder; 97 launches per token step)"
+    roofline_lm = {"bound": "hbm", "kernel": kname,
                    "achieved": round(gb_t, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gb_t / PEAK_HBM_GBPS, 4),
-                   "traffic": _pmc("r03_bench_pmc.json", "kernels", "gemv32_k", "traffic_bytes"),
-                   "traffic_unit": "HBM-side bytes per launch, mean over every gemv32_k launch of the run (rocprofv3 --pmc over bench.py itself: profiles/r03_bench_pmc.json); above the weights by the A images each XCD's L2 fetches once and the split-K partial tiles",
+                   "traffic": _pmc("r04_bench_pmc.json", "kernels", "llm_decode32_k" if lm32 else "gemv32_k", "traffic_bytes"),
+                   "traffic_unit": "HBM-side bytes per launch, mean over every launch of the run (rocprofv3 --pmc over bench.py itself: profiles/r04_bench_pmc.json)",
                    "launches": n_vt, "avg_launch_us": round(1e3 * ms_vt / max(n_vt, 1), 2), "algorithmic_bytes_per_launch": int(bytes_vt / max(n_vt, 1)),
                    "measured_over": where_t,
-                   "one_generation_alone": {"achieved": round(gb_a, 1), "frac": round(gb_a / PEAK_HBM_GBPS, 4), "avg_launch_us": round(1e3 * ms_v / max(n_v, 1), 2), "launches": n_v,
-                                            "generate_ms": round(lm_ms, 2), "rows": BATCH * G, "ms_per_token_step": round(lm_ms / N_TOK, 4),
-                                            "weight_GBps_at_token_step_level": round(step_bytes / (lm_ms / N_TOK * 1e-3) / 1e9, 1),
-                                            "note": "one LM call alone (prefill included in generate_ms); a token step is 122 dependent launches: latency-bound, not bandwidth-bound"}}
+                   "one_generation_alone": alone32 if lm32 else alone_ops,
+                   "per_operation_products_alone": alone_ops,
+                   "note": "alone: one LM call of 32 sequences with nothing else on the GPU (prefill included in generate_ms)"}
 
     # ---- the same decode as ONE persistent launch per token step (llm_decode.hip; what tts / tts_batch / stream=True use for up
     # to 8 sequences): HIP events around every launch of a generation run alone.
@@ -592,8 +608,8 @@ def main():
         roofline_lm_p = {"bound": "hbm", "kernel": "llm_decode_k: one persistent launch per token step (24 layers + llm_decoder, 152 workgroups, "
                          "weights register-resident a layer ahead, 121 grid-wide hand-offs)", "achieved": round(gb, 1), "peak": PEAK_HBM_GBPS,
                          "unit": "GB/s", "frac": round(gb / PEAK_HBM_GBPS, 4),
-                         "traffic": _pmc("r03_bench_pmc.json", "kernels", "llm_decode_k", "traffic_bytes"),
-                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc over bench.py itself: profiles/r03_bench_pmc.json, kernels.llm_decode_k.traffic_bytes)",
+                         "traffic": _pmc("r04_bench_pmc.json", "kernels", "llm_decode_k", "traffic_bytes"),
+                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc over bench.py itself: profiles/r04_bench_pmc.json, kernels.llm_decode_k.traffic_bytes)",
                          "launches": n_p, "avg_launch_us": round(1e3 * ms_p / max(n_p, 1), 1), "algorithmic_bytes_per_launch": int(bytes_p / max(n_p, 1)),
                          "generate_ms_batch8_75_tokens": round(lm_p_ms, 2),
                          "measured_over": "HIP events on the launch stream around every launch of one 75-token generation at batch 8, run alone"}

@@ -126,6 +126,7 @@ def _declare(L):
     L.fy_llm_set_decode_mode.argtypes = [vp, i32]
     L.fy_llm_decode_mode.argtypes = [vp]
     L.fy_debug_decode_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
+    L.fy_debug_decode32_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
 
 
 def tensor_table(weights):

@@ -12,6 +12,7 @@
 #include "gemm.h"
 #include "gemv32.h"
 #include "llm_decode.h"
+#include "llm_decode32.h"
 #include "runtime.h"
 #include <algorithm>
 #include <math.h>
@@ -51,6 +52,7 @@ struct fy_llm {
     int prefill_gemm_rows = 320;           // FY_LLM_PREFILL_GEMM_ROWS: from this many prefill rows on, the tiled GEMMs
     bool prefill_gemm = true;              // FY_LLM_PREFILL_GEMM=0 keeps the 8-row products for the prefill too (A/B measurements)
     int decode_mode = 1;                   // fy_llm_set_decode_mode: 1 = use it, 0 = one launch per operation
+    Dec32Plan* dec32 = nullptr;            // persistent decode step for 9 .. 32 sequences on a few CUs (llm_decode32.hip), same switch
     // per-operation products that serve 32 rows per weight pass (gemv32.h; FY_LLM_GEMV32=0 keeps the 8-row products of gemm.h):
     // the operands travel as A images written by the producers' epilogues
     bool gv32 = true;
@@ -461,7 +463,7 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
     fy_llm* l = new fy_llm();
     if (cfg) l->cfg = *cfg; else fy_llm_default_config(&l->cfg);
     const fy_llm_config& c = l->cfg;
-    auto fail = [&](int code) { if (l->dec) decode_destroy(l->dec); delete l; return code; };
+    auto fail = [&](int code) { if (l->dec) decode_destroy(l->dec); if (l->dec32) decode32_destroy(l->dec32); delete l; return code; };
     if (c.head_dim != 64 || c.q_heads % c.kv_heads != 0 || c.hidden % 8 != 0 || c.inter % 8 != 0 || c.q_heads * c.head_dim != c.hidden) {
         fy_set_error("fy_llm_create: unsupported architecture (hidden %d, heads %d/%d x %d)", c.hidden, c.q_heads, c.kv_heads, c.head_dim);
         return fail(FY_ERR_ARG);
@@ -572,6 +574,20 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
             return fail(FY_ERR_HIP);
         }
     } else TRYC(l->pool.alloc(&l->act_split, ((R + 7) / 8) * 24 * (size_t)I));
+    if (l->gv32 && max_batch > 8) {
+        // the few-CU persistent step for 9 .. 32 sequences shares the per-operation path's weights, images and scratch
+        Dec32Shape s32;
+        s32.H = H; s32.I = I; s32.Hq = c.q_heads; s32.Hk = c.kv_heads; s32.layers = c.layers; s32.NS = NS; s32.max_ctx = max_ctx; s32.mb = max_batch; s32.eps = c.rms_eps;
+        if (decode32_supported(s32)) {
+            std::vector<Dec32Layer> ly(c.layers);
+            for (int i = 0; i < c.layers; ++i) {
+                const LlmLayerW& k = l->L[i];
+                ly[i].wqkv = k.wqkv; ly[i].wo = k.wo; ly[i].wgu = k.wgu; ly[i].wd = k.wd; ly[i].bqkv = k.bqkv; ly[i].ln1 = k.ln1; ly[i].ln2 = k.ln2;
+                ly[i].Kc = l->Kc + (size_t)i * l->cache_layer(); ly[i].Vc = l->Vc + (size_t)i * l->cache_layer();
+            }
+            TRYC(decode32_create(&l->dec32, s32, ly.data(), l->w_head, l->norm_w, st));
+        }
+    }
     TRYC(l->pool.alloc(&l->logits, B * NS)); TRYC(l->pool.alloc(&l->partial, gemv_partial_floats((int)R, H, I) + 16));
     TRYC(l->pool.alloc(&l->counters, gemv_counter_ints((int)R, H, I) + 16));
     if (hipMemsetAsync(l->counters, 0, (gemv_counter_ints((int)R, H, I) + 16) * sizeof(int), st) != hipSuccess) { fy_set_error("fy_llm_create: memset failed"); return fail(FY_ERR_HIP); }
@@ -599,6 +615,7 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
 extern "C" void fy_llm_destroy(fy_llm* l) {
     if (l && l->recent) (void)hipFree(l->recent);
     if (l && l->dec) decode_destroy(l->dec);
+    if (l && l->dec32) decode32_destroy(l->dec32);
     delete l;
 }
 
@@ -850,11 +867,13 @@ extern "C" int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t
     unsigned dec_status = 0;
     int step = l->step_next;
     const bool persistent = l->dec && l->decode_mode == 1 && B <= 8;
+    const bool persistent32 = !persistent && l->dec32 && l->decode_mode == 1 && B <= 32;
     auto read_done = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
         // only a call that used the persistent step looks at (and clears) its time-out word: a time-out is reported once,
         // and the handle then works on the per-operation path (fy_llm_set_decode_mode(0)) as the message says
         if (persistent) FY_TRY(decode_status(l->dec, &dec_status, st));
+        if (persistent32) FY_TRY(decode32_status(l->dec32, &dec_status, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (dec_status != 0) {
             l->step_next = 0;                // the generation is void: no further steps are launched on it
@@ -867,6 +886,9 @@ extern "C" int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t
     for (; step < end; ++step) {
         if (persistent) {                    // the 24 layers + llm_decoder of the step in one launch, then the sampler
             FY_TRY(decode_step(l->dec, B, l->h, l->st, l->inv_freq, l->logits, st));
+            FY_TRY(llm_sample(l, B, out_ids, out_ld, step, st));
+        } else if (persistent32) {           // the same in one launch on a few CUs for up to 32 sequences (operands: the 32-row path's images)
+            FY_TRY(decode32_step(l->dec32, B, l->h, l->img_h, l->ssq, l->qkv, l->img_ao, l->st, l->inv_freq, l->logits, st));
             FY_TRY(llm_sample(l, B, out_ids, out_ld, step, st));
         } else {
             FY_TRY(llm_layers(l, B, l->seq_ids, l->st, true, st));
@@ -946,10 +968,15 @@ extern "C" int fy_debug_decode_stamps(fy_llm* l, unsigned long long* out, int32_
     return decode_stamps(l->dec, out, n, (hipStream_t)stream);
 }
 
+extern "C" int fy_debug_decode32_stamps(fy_llm* l, unsigned long long* out, int32_t n, void* stream) {
+    FY_CHECK(l && l->dec32, FY_ERR_STATE, "fy_debug_decode32_stamps: this handle has no 32-row persistent decode plan");
+    return decode32_stamps(l->dec32, out, n, (hipStream_t)stream);
+}
+
 extern "C" int fy_llm_set_decode_mode(fy_llm* l, int32_t mode) {
     FY_CHECK(l && (mode == 0 || mode == 1), FY_ERR_ARG, "fy_llm_set_decode_mode: mode must be 0 (one launch per operation) or 1 (persistent step)");
     l->decode_mode = mode;
     return FY_OK;
 }
 
-extern "C" int fy_llm_decode_mode(const fy_llm* l) { return l && l->dec && l->decode_mode == 1 ? 1 : 0; }
+extern "C" int fy_llm_decode_mode(const fy_llm* l) { return l && (l->dec || l->dec32) && l->decode_mode == 1 ? 1 : 0; }

@@ -107,6 +107,46 @@ def test_many_rows_per_weight_pass(size, n_rows):
         eng.close()
 
 
+@pytest.mark.parametrize("size,n_rows", [("tiny", 9), ("tiny", 20), ("tiny", 32), ("full", 12), ("full", 32)])
+def test_persistent_step_for_up_to_32_rows(size, n_rows):
+    """The few-CU persistent decode step (llm_decode32.hip: one launch per token step for 9 .. 32 sequences, 38 workgroups at full
+    size) against the reference fixtures: every row emits its case's ids, whatever slot it sits in; and a generation that switches
+    between this step and the per-operation launches mid-way (they share operands and layouts) emits the same ids."""
+    cfg = LlmCfg.tiny() if size == "tiny" else LlmCfg()
+    f = golden(f"llm_{size}.npz")
+    if f is None:
+        pytest.skip(f"llm_{size}.npz not minted")
+    base = [(12, 8, 0), (10, 6, 30)] if size == "tiny" else [(12, 8, 0), (14, 10, 40)]
+    cap = None if size == "tiny" else 40
+    eng = make(cfg, max_batch=n_rows, max_ctx=512 if size == "tiny" else 160)
+    try:
+        eng.set_decode_mode(True)
+        assert eng.persistent
+        cases = [base[(b * 7 // 3) % 2] for b in range(n_rows)]
+        texts, ptexts, ptoks = (list(x) for x in zip(*[llm_case(cfg, *c, "%d_%d_%d" % c) for c in cases]))
+        max_len = [cap if cap else int(len(t) * 20) for t in texts]
+        out, out_n, _ = eng.generate(texts, ptexts, ptoks, max_len=max_len)
+        out, out_n = out.cpu().clone(), out_n.cpu().tolist()
+        for b, c in enumerate(cases):
+            ref = f["c%d_%d_%d.tokens" % c].tolist()
+            ref = ref[:cap] if cap else ref
+            assert out[b, : out_n[b]].tolist() == ref, (b, c)
+        # the same generation in pieces, alternating between the persistent step and the per-operation launches
+        out2, _, _ = eng.begin(texts, ptexts, ptoks, max_len=max_len)
+        fin, k = [False], 0
+        while not all(fin):
+            eng.set_decode_mode(k % 2 == 0)
+            n, fin = eng.step(5)
+            k += 1
+            assert k < 400
+        assert n == out_n
+        out2 = out2.cpu()
+        for b in range(n_rows):
+            assert out2[b, : n[b]].tolist() == out[b, : n[b]].tolist(), b
+    finally:
+        eng.close()
+
+
 def test_eight_row_products_equal_the_32_row_products(monkeypatch):
     """FY_LLM_GEMV32=0 keeps the 8-row products of gemm.hip on the per-operation path (operands staged and split in every block,
     one weight pass per 8 rows): same ids and first log-probabilities as the 32-row products, tiny and full size."""
