@@ -43,6 +43,7 @@ FY_PRECISE = 1
 FY_DIRECT = 2
 FY_STREAMING = 4
 FY_NO_FINALIZE = 8
+FY_INCREMENTAL = 16
 FY_LLM_KEEP_LOGP = 4
 
 _lib = None
@@ -92,6 +93,7 @@ def _declare(L):
     L.fy_flow_destroy.argtypes = [vp]
     L.fy_flow_destroy.restype = None
     L.fy_flow_infer.argtypes = [vp, vp, i32, i32p, vp, i32, i32p, f32p, i32, i32p, f32p, f32p, i32, i32, f32p, i32, u32, vp]
+    L.fy_flow_stream_reset.argtypes = [vp]
     L.fy_dit_estimator.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, f32p, i32, i32, u32, vp]
     L.fy_llm_default_config.argtypes = [C.POINTER(LlmConfig)]
     L.fy_llm_default_config.restype = None

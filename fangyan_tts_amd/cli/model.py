@@ -33,7 +33,7 @@ class CosyVoice3Model:
                  rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
                  sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False, n_llm: int = 1,
                  sampler: str = "greedy", sampler_seed: int = 1986, lm_group: int = 1, concurrency: int = 1, flow_workers: int = 1,
-                 flow_group: int = 1, cache_prompts: bool = True):
+                 flow_group: int = 1, cache_prompts: bool = True, incremental_stream: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -44,6 +44,11 @@ class CosyVoice3Model:
         # kernel writing through data_ptr()): callers that do that, or that never repeat a prompt, pass False - every call then
         # pads and copies its prompts afresh.
         self.cache_prompts = bool(cache_prompts)
+        # stream=True: the intermediate chunks push only their NEW mel rows through the DiT blocks, against the keys / values the
+        # earlier chunks left per (Euler step, block) (csrc/flow.hip: FY_INCREMENTAL) - exact under the chunk mask, because the
+        # reference's schedule ends every chunk on a mask boundary; the reference itself (and False here) re-runs the flow decoder
+        # over everything so far for every chunk (cli/model.py:339-369).  The last call (no mask) is always a full pass.
+        self.incremental_stream = bool(incremental_stream)
         self.max_batch, self.max_tokens, self.max_prompt_tokens = max_batch, max_tokens, max_prompt_tokens
         max_frames = 2 * (max_tokens + max_prompt_tokens)
         # n_llm > 1: extra LM handles (own KV cache and workspace) so tts_pipeline can decode several batches at once;
@@ -625,10 +630,12 @@ class CosyVoice3Model:
                     n, done = out.shape[1], True
             pad = -(-n_fp // hop0) * hop0 - n_fp
             offset, speech_offset, mel_all = 0, 0, None
+            ln.flow.stream_reset()                          # the incremental flow calls of this stream start from nothing
 
             def token2wav(n_in, offset, mel_all, speech_offset, streaming, finalize):
                 mel = ln.flow.inference(out[:, :n_in], [n_in], ptok, [n_fp], pfeat, [n_pf], emb, self.rand_noise,
-                                        streaming=streaming, finalize=finalize, flags=self.flow_flags)
+                                        streaming=streaming, finalize=finalize, flags=self.flow_flags,
+                                        incremental=self.incremental_stream and streaming and not finalize)
                 valid = 2 * (n_in if finalize else n_in - look)
                 mel = mel[:, :, 2 * offset: valid]
                 mel_all = mel if mel_all is None else torch.cat([mel_all, mel], dim=2)

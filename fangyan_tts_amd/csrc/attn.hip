@@ -28,7 +28,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // qkv: bf16 [nseq*Tmax][3*H*64] as [q | k | v]; out: bf16 [nseq*Tmax][H*64]
 template <int AT_NW, int WPE>
 __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void dit_attention_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                              const int* __restrict__ seq_len, int Tmax, int H, int chunk, float scale_log2) {
+                                                              const int* __restrict__ seq_len, int Tmax, int H, int chunk, float scale_log2, int q_begin) {
     __shared__ __attribute__((aligned(16))) bf16_t Kbuf[2][64 * AT_KP];      // two tiles: the next one is written while this one is read,
     __shared__ __attribute__((aligned(16))) bf16_t Vbuf[2][64 * AT_VP];      // one barrier per key tile
     // the many-wave form runs at 4 waves per SIMD (128 registers): the query fragments wait in LDS instead of 16 registers
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE,
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int s = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * (AT_NW * 32);
     const int len = seq_len[s];
-    if (q0 >= len) return;
+    if (q0 >= len || q0 + AT_NW * 32 <= q_begin) return;     // q_begin: only the queries from that row on are wanted (incremental streaming)
     const int ld = 3 * H * AT_D;
     const bf16_t* base = qkv + (long)s * Tmax * ld;
     const int lr = lane & 31, hf = lane >> 5;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE,
         if (more) store_kv((it + 1) & 1);                    // that buffer was last read before the previous barrier
         __syncthreads();
     }
-    if (qrow >= len) return;
+    if (qrow >= len || qrow < q_begin) return;
     const float inv = 1.f / l_run;
     bf16_t* op = out + ((long)s * Tmax + qrow) * (H * AT_D) + h * AT_D;
 #pragma unroll
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE,
         }
 }
 
-int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st) {
+int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st, int q_begin) {
     FY_CHECK(qkv && out && seq_len && nseq >= 1 && Tmax >= 1 && H >= 1, FY_ERR_ARG, "dit_attention: bad arguments");
     const float sl2 = 0.125f * 1.4426950408889634f;
     static int cus = 0;
@@ -215,13 +215,13 @@ int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, 
     const int nw = cdiv(Tmax, 32);
     int W = 4;                                                   // waves per workgroup
     if (force) W = force;
-    else if (nw >= 8 && nw <= 16 && H * nseq >= cus / 2) W = nw;
+    else if (nw >= 8 && nw <= 16 && H * nseq >= cus / 2 && q_begin == 0) W = nw;
     if (W <= 4) {
         dim3 grid(cdiv(Tmax, 4 * 32), H, nseq);
-        hipLaunchKernelGGL((dit_attention_k<4, 3>), grid, dim3(4 * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2);
+        hipLaunchKernelGGL((dit_attention_k<4, 3>), grid, dim3(4 * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2, q_begin);
     } else {
         dim3 grid(cdiv(nw, W), H, nseq);
-#define FY_ATT_CASE(N) case N: hipLaunchKernelGGL((dit_attention_k<N, 4>), grid, dim3(N * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2); break;
+#define FY_ATT_CASE(N) case N: hipLaunchKernelGGL((dit_attention_k<N, 4>), grid, dim3(N * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2, q_begin); break;
         switch (W) {
             FY_ATT_CASE(8) FY_ATT_CASE(9) FY_ATT_CASE(10) FY_ATT_CASE(11) FY_ATT_CASE(12)
             FY_ATT_CASE(13) FY_ATT_CASE(14) FY_ATT_CASE(15) FY_ATT_CASE(16)

@@ -40,6 +40,11 @@ struct fy_flow {
     // lo planes of the fp32-class mode (FY_PRECISE): every GEMM operand travels as x = hi + lo, the hi plane in the default mode's
     // own buffer (a_in, xn, qkv, ao, ff: hi = bf16(x) is exactly what the default mode stores), the lo plane here; allocated on first use
     bf16_t *a_in_lo = nullptr, *xn_lo = nullptr, *qkv_lo = nullptr, *ao_lo = nullptr, *ff_lo = nullptr;
+    // incremental streaming (FY_INCREMENTAL, batch 1): the q | k | v rows of every (Euler step, block) as they were computed -
+    // [n_steps][depth][2 Tmax][3 inner] bf16 - and the ODE state at every step, [(n_steps + 1)][Tmax][mel] fp32; inc_T = rows kept
+    bf16_t* inc_qkv = nullptr;
+    float* inc_x = nullptr;
+    int inc_T = 0;
     ~fy_flow() { conv_free(pre1); conv_free(pre2); conv_free(pos1); conv_free(pos2); }
 };
 
@@ -184,8 +189,8 @@ __global__ __launch_bounds__(256) void ln_mod_k(const float* __restrict__ h, con
 }
 
 // CFG mix and Euler update, flow_matching.py:114-118
-__global__ void euler_k(float* __restrict__ x, const float* __restrict__ v, const int* __restrict__ T, int Tmax, int C, float dt, float cfg) {
-    int b = blockIdx.y, t = blockIdx.x, c = threadIdx.x;
+__global__ void euler_k(float* __restrict__ x, const float* __restrict__ v, const int* __restrict__ T, int Tmax, int C, float dt, float cfg, int t0) {
+    int b = blockIdx.y, t = t0 + blockIdx.x, c = threadIdx.x;
     if (t >= T[b] || c >= C) return;
     float vc = v[((long)(2 * b) * Tmax + t) * C + c], vu = v[((long)(2 * b + 1) * Tmax + t) * C + c];
     float d = (1.0f + cfg) * vc - cfg * vu;
@@ -473,6 +478,94 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
     return FY_OK;
 }
 
+// the caches of the incremental streaming path, on first use: 2 x Tmax x 3 inner bf16 per (step, block) - 2.7 MB per frame row
+// of capacity at full size - and the ODE states; an allocation failure just means "not incremental"
+static int inc_alloc(fy_flow* f) {
+    if (f->inc_qkv && f->inc_x) return FY_OK;
+    const fy_flow_config& c = f->cfg;
+    const size_t nq = (size_t)c.n_timesteps * c.depth * 2 * f->Tmax * 3 * c.heads * c.head_dim, nx = (size_t)(c.n_timesteps + 1) * f->Tmax * c.mel;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < nq * 2 + nx * 4 + ((size_t)1 << 30)) return FY_ERR_HIP;
+    if (!f->inc_qkv && f->pool.alloc(&f->inc_qkv, nq) != FY_OK) return FY_ERR_HIP;
+    if (!f->inc_x && f->pool.alloc(&f->inc_x, nx) != FY_OK) return FY_ERR_HIP;
+    f->inc_T = 0;
+    return FY_OK;
+}
+
+// The incremental form of dit_forward for a streaming chunk at batch 1 (two sequences: conditional and CFG branch): the input
+// projection and the causal position convs run over all T rows (cheap, and they need the rows to the left), then ONLY the rows
+// [T0, T) go through the blocks - per sequence, in place in the full-size buffers (row s Tmax + t) - while attention reads the
+// keys / values of the earlier rows from the (step, block) slice of inc_qkv, into which the qkv product of the new rows writes
+// directly.  Under the chunk mask with T0 and T on chunk boundaries the rows before T0 see nothing of the new ones, so their
+// keys, values and outputs are what the previous call computed: same bits as the full recompute (test).
+// Every buffer is addressed at the handle's CAPACITY pitch here (row s f->Tmax + t), so that a row keeps its place from call to call.
+static int dit_forward_inc(fy_flow* f, int step, int T0, int T, hipStream_t st) {
+    const fy_flow_config& c = f->cfg;
+    const int D = c.dim, C = c.mel, inner = c.heads * c.head_dim, FF = D * c.ff_mult, nseq = 2, Tc = T - T0, Tmax = f->Tmax;
+    const int M = nseq * Tmax;
+    GemmEpi e;
+    e.bias = f->b_in; e.out = f->h; e.out_bf16 = 0; e.ldc = D;
+    FY_TRY(gemm_bf16(f->a_in, 4 * C, f->w_in, M, D, 4 * C, e, st));
+    {
+        ConvDesc d;
+        memset(&d, 0, sizeof(d));
+        d.B = nseq; d.dil = 1; d.stride = 1; d.up = 1; d.groups = c.conv_pos_groups; d.out_scale = 1.f;
+        d.x = f->h; d.x_bs = (long)Tmax * D; d.x_ld = D; d.L_in = Tmax; d.in_len = f->seq_len;
+        d.y = f->c1; d.y_bs = (long)Tmax * D; d.y_ld = D; d.L_out = Tmax; d.out_len = f->seq_len;
+        d.Cin = D; d.Cout = D; d.KW = c.conv_pos_k; d.pad_left = c.conv_pos_k - 1; d.bias = f->pos1.bias; d.post_act = ACT_MISH;
+        const bool mf = f->pos1.w_mfma != nullptr;
+        FY_TRY(mf ? conv1d_bf16_mfma(d, f->pos1, false, st) : conv1d_f32_direct(d, f->pos1, st));
+        d.x = f->c1; d.y = f->h; d.bias = f->pos2.bias;
+        d.add_resid = 1; d.resid = f->h; d.r_bs = (long)Tmax * D; d.r_ld = D;
+        FY_TRY(mf ? conv1d_bf16_mfma(d, f->pos2, false, st) : conv1d_f32_direct(d, f->pos2, st));
+    }
+    const float* modbase = f->mod + (size_t)step * c.depth * 6 * D;
+    const size_t slice = (size_t)nseq * f->Tmax * 3 * inner;                 // one (step, block) slice of inc_qkv, rows at the handle's Tmax pitch
+    for (int i = 0; i < c.depth; ++i) {
+        const FlowBlockW& k = f->blk[i];
+        const float* m = modbase + (size_t)i * 6 * D;
+        bf16_t* qkv = f->inc_qkv + ((size_t)step * c.depth + i) * slice;
+        for (int s = 0; s < nseq; ++s) {
+            const size_t r0 = (size_t)s * Tmax + T0;
+            hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(Tc, 4)), dim3(256), 0, st, f->h + r0 * D, m + D, m, f->xn + r0 * D, (bf16_t*)nullptr, Tc, D);
+            GemmEpi q;
+            q.bias = k.bqkv; q.out = qkv + r0 * 3 * inner; q.out_bf16 = 1; q.ldc = 3 * inner;
+            q.rope = f->rope + (size_t)T0 * (c.head_dim / 2); q.rope_T = Tc; q.rope_half = c.head_dim / 2; q.rope_stride = inner;
+            FY_TRY(gemm_bf16(f->xn + r0 * D, D, k.wqkv, Tc, 3 * inner, D, q, st));
+        }
+        FY_TRY(dit_attention(qkv, f->ao, f->seq_len, nseq, Tmax, c.heads, c.static_chunk, st, T0));
+        for (int s = 0; s < nseq; ++s) {
+            const size_t r0 = (size_t)s * Tmax + T0;
+            GemmEpi o;
+            o.mode = EPI_GATE_RESID; o.bias = k.bo; o.resid = f->h + r0 * D; o.gate = m + 2 * D; o.ldc = D;
+            FY_TRY(gemm_bf16(f->ao + r0 * inner, inner, k.wo, Tc, D, inner, o, st));
+            hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(Tc, 4)), dim3(256), 0, st, f->h + r0 * D, m + 4 * D, m + 3 * D, f->xn + r0 * D, (bf16_t*)nullptr, Tc, D);
+            GemmEpi g;
+            g.bias = k.b1; g.act = ACT_GELU_TANH; g.out = f->ff + r0 * FF; g.out_bf16 = 1; g.ldc = FF;
+            FY_TRY(gemm_bf16(f->xn + r0 * D, D, k.w1, Tc, FF, D, g, st));
+            GemmEpi r;
+            r.mode = EPI_GATE_RESID; r.bias = k.b2; r.resid = f->h + r0 * D; r.gate = m + 5 * D; r.ldc = D;
+            FY_TRY(gemm_bf16(f->ff + r0 * FF, FF, k.w2, Tc, D, FF, r, st));
+        }
+    }
+    const float* fn = f->fin + (size_t)step * 2 * D;
+    for (int s = 0; s < nseq; ++s) {
+        const size_t r0 = (size_t)s * Tmax + T0;
+        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(Tc, 4)), dim3(256), 0, st, f->h + r0 * D, fn, fn + D, f->xn + r0 * D, (bf16_t*)nullptr, Tc, D);
+        GemmEpi p;
+        p.bias = f->b_out; p.out = f->v + r0 * C; p.out_bf16 = 0; p.ldc = C;
+        FY_TRY(gemm_bf16(f->xn + r0 * D, D, f->w_out, Tc, C, D, p, st));
+    }
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+extern "C" int fy_flow_stream_reset(fy_flow* f) {
+    FY_CHECK(f, FY_ERR_ARG, "fy_flow_stream_reset: null handle");
+    f->inc_T = 0;
+    return FY_OK;
+}
+
 extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, const int32_t* n_token, const int32_t* prompt_token,
                              int32_t ptok_ld, const int32_t* n_prompt, const float* prompt_feat, int32_t pfeat_rows, const int32_t* n_pfeat,
                              const float* embedding, const float* rand_noise, int32_t noise_ld, int32_t B, float* mel, int32_t mel_frames,
@@ -526,11 +619,35 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
     hipLaunchKernelGGL(flow_setup_k, dim3(Tmax, B), dim3(128), 0, st, f->mu_tok, prompt_feat, (long)pfeat_rows * C, rand_noise, noise_ld, d_T,
                        d_pmel, f->mu, f->cond, f->x, Tmax, Nmax, C);
     if (flags & FY_PRECISE) FY_TRY(ensure_precise(f));
+    // FY_INCREMENTAL (a streaming chunk at batch 1, bf16 mode): T0 = rows the previous call of this stream left (0: none, or not on
+    // a chunk boundary - everything is computed, and kept for the next call)
+    const bool inc = (flags & FY_INCREMENTAL) && B == 1 && (flags & FY_STREAMING) && (flags & FY_NO_FINALIZE) && !(flags & (FY_PRECISE | FY_DIRECT)) &&
+                     c.static_chunk > 0 && Tmax % c.static_chunk == 0 && inc_alloc(f) == FY_OK;
+    if (inc) {
+        int T0 = f->inc_T;
+        if (T0 % c.static_chunk != 0 || T0 >= Tmax) T0 = 0;
+        float* xs = f->inc_x;
+        const size_t xslice = (size_t)f->Tmax * C;
+        for (int step = 0; step < c.n_timesteps; ++step) {
+            // the state at this step: the earlier rows as the previous calls left them, the new rows as they evolve in f->x
+            HIP_TRY(hipMemcpyAsync(xs + step * xslice + (size_t)T0 * C, f->x + (size_t)T0 * C, (size_t)(Tmax - T0) * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(dit_assemble_k, dim3(f->Tmax, 2), dim3(4 * C), 0, st, xs + step * xslice, f->cond, f->mu, f->spks, d_T, f->a_in, (bf16_t*)nullptr, f->Tmax, C);
+            FY_TRY(dit_forward_inc(f, step, T0, Tmax, st));
+            hipLaunchKernelGGL(euler_k, dim3(Tmax - T0, 1), dim3(128), 0, st, f->x, f->v, d_T, f->Tmax, C, f->dt_of_step[step], c.cfg_rate, T0);
+        }
+        HIP_TRY(hipMemcpyAsync(xs + c.n_timesteps * xslice + (size_t)T0 * C, f->x + (size_t)T0 * C, (size_t)(Tmax - T0) * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+        f->inc_T = Tmax;
+        const int F = 2 * (n_token[0] + n_prompt[0] - look) - n_pfeat[0];
+        FY_TRY(transpose_blc_to_bcl(xs + c.n_timesteps * xslice + (size_t)n_pfeat[0] * C, mel, 1, C, F, 0, C, 0, mel_frames, st));
+        HIP_TRY(hipGetLastError());
+        return FY_OK;
+    }
+    if (flags & FY_INCREMENTAL) f->inc_T = 0;             // a call that could not be incremental breaks the stream
     for (int step = 0; step < c.n_timesteps; ++step) {
         hipLaunchKernelGGL(dit_assemble_k, dim3(Tmax, 2 * B), dim3(4 * C), 0, st, f->x, f->cond, f->mu, f->spks, d_T, f->a_in,
                            (flags & FY_PRECISE) ? f->a_in_lo : nullptr, Tmax, C);
         FY_TRY(dit_forward(f, 2 * B, Tmax, step, (flags & FY_STREAMING) != 0, flags, st));
-        hipLaunchKernelGGL(euler_k, dim3(Tmax, B), dim3(128), 0, st, f->x, f->v, d_T, Tmax, C, f->dt_of_step[step], c.cfg_rate);
+        hipLaunchKernelGGL(euler_k, dim3(Tmax, B), dim3(128), 0, st, f->x, f->v, d_T, Tmax, C, f->dt_of_step[step], c.cfg_rate, 0);
     }
     // mel[b] = x[b][pmel:, :]^T in the reference's (B, 80, F) layout, flow.py:401
     for (int b = 0; b < B; ++b) {

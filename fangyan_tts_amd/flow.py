@@ -65,11 +65,15 @@ class FlowEngine:
 
     def inference(self, token: torch.Tensor, n_token: Sequence[int], prompt_token: torch.Tensor, n_prompt: Sequence[int],
                   prompt_feat: torch.Tensor, n_pfeat: Sequence[int], embedding: torch.Tensor, rand_noise: torch.Tensor,
-                  flags: int = 0, streaming: bool = False, finalize: bool = True) -> torch.Tensor:
+                  flags: int = 0, streaming: bool = False, finalize: bool = True, incremental: bool = False) -> torch.Tensor:
         """token (B, Nmax) int32, prompt_token (B, Pmax) int32, prompt_feat (B, PMmax, 80), embedding (B, 192),
         rand_noise (1|-, 80, >=T) -> mel (B, 80, 2*max(n_token)); utterance b is valid in [:, :, :2*n_token[b]].
         streaming / finalize as in the reference (flow.py:358-403): the chunk attention mask, and the last
-        pre_lookahead tokens as look-ahead context only (valid frames 2*(n_token[b] - pre_lookahead))."""
+        pre_lookahead tokens as look-ahead context only (valid frames 2*(n_token[b] - pre_lookahead)).
+        incremental (with streaming, finalize=False, one utterance): this call extends the previous incremental call of the handle -
+        only the new rows go through the DiT blocks (FY_INCREMENTAL; `stream_reset` starts a new stream).  Same result."""
+        if incremental:
+            flags |= _lib.FY_INCREMENTAL
         if streaming:
             flags |= FY_STREAMING
         if not finalize:
@@ -93,6 +97,10 @@ class FlowEngine:
                                        embedding.data_ptr(), noise.data_ptr(), noise.shape[1], B, mel.data_ptr(), frames,
                                        flags, self._stream()))
         return mel
+
+    def stream_reset(self):
+        """Forget what incremental calls have kept: the next one starts a new stream."""
+        check(_lib.lib().fy_flow_stream_reset(self._h))
 
     def speed(self, mel: torch.Tensor, speed: float) -> torch.Tensor:
         """cli/model.py:435-437: F.interpolate(mel, size=int(F / speed), mode="linear") on (B, 80, F)."""

@@ -57,6 +57,11 @@ int fy_stream_destroy(void* stream);
 #define FY_PRECISE 1u /* split-bf16 (hi+lo) activations on the MFMA paths: fp32-class accuracy, 2x MFMA work */
 #define FY_DIRECT 2u  /* HiFT / DiT position conv: run convolutions on the exact fp32 VALU kernel */
 #define FY_STREAMING 4u /* flow: block-causal chunk attention mask (streaming=True in the reference) */
+#define FY_INCREMENTAL 16u /* flow, with FY_STREAMING | FY_NO_FINALIZE and B = 1: this call extends the previous FY_INCREMENTAL call of the
+                             handle (same prompt, the earlier tokens a prefix): only the new rows go through the DiT blocks, against the
+                             keys / values of the earlier rows kept per (Euler step, block).  Exact under the chunk mask when both calls end
+                             on a chunk boundary (the reference's schedule does); otherwise, and after fy_flow_stream_reset, everything is
+                             computed (and kept).  Same results as without the flag.                                                    */
 #define FY_NO_FINALIZE 8u /* flow, HiFT: a streaming chunk (finalize=False in the reference): the last tokens / frames are
                             look-ahead context, not output (flow: pre_lookahead tokens; HiFT: 3 + 4 frames and 480 samples) */
 
@@ -133,6 +138,9 @@ int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, const int32_
                   int32_t ptok_ld, const int32_t* n_prompt, const float* prompt_feat, int32_t pfeat_rows, const int32_t* n_pfeat,
                   const float* embedding, const float* rand_noise, int32_t noise_ld, int32_t B, float* mel, int32_t mel_frames,
                   uint32_t flags, void* stream);
+
+/* forget what FY_INCREMENTAL calls have kept: the next one starts a new stream (call it when a stream=True generation begins) */
+int fy_flow_stream_reset(fy_flow* f);
 
 /* replaces the estimator hand-off ConditionalCFM.forward_estimator uses for a non-nn.Module estimator
  *   cosyvoice/flow/flow_matching.py:126-153: contiguous x (B2,80,T), mask (B2,1,T), mu (B2,80,T), t (B2),

@@ -18,13 +18,12 @@ cfg = dataclasses.replace(LlmCfg(), vocab=2048)        # the text-embedding tabl
 man = {k: v for k, v in cfg.manifest().items() if "lm_head" not in k}
 sd = {k: torch.from_numpy(v).cuda() for k, v in synth.state_dict(man).items()}
 print("weights on the GPU", flush=True)
-for persistent in (True, False):
-    B = 8 if persistent else 32             # the per-operation path serves 32 rows per weight pass (gemv32.hip)
+for persistent, B in ((True, 8), (True, 32), (False, 32)):       # 8-row persistent step; few-CU 32-row persistent step; per-operation products at 32 rows
     text = [[(7 * i + b) % 2000 for i in range(12 + b % 9)] for b in range(B)]
     ptext = [[(11 * i + b) % 2000 for i in range(8)] for b in range(B)]
     eng = LlmEngine(sd, cfg, max_batch=B, max_ctx=256)
     eng.set_decode_mode(persistent)
     out, n, _ = eng.generate(text, ptext, [[] for _ in range(B)], min_len=[6] * B, max_len=[6] * B)
     torch.cuda.synchronize()
-    print("persistent" if persistent else "per-op", out[0, :6].tolist(), flush=True)
+    print("persistent" if persistent else "per-op", B, out[0, :6].tolist(), flush=True)
     eng.close()

@@ -181,3 +181,38 @@ def test_flow_chunked_equals_whole():
         worst = max(worst, maxerr(m[:, :, 2 * i: n_out], gt[:, :, 2 * i: n_out]))
     note("parity_stream.json", "flow.chunked_vs_whole", worst)
     assert worst <= 1e-5, worst                              # measured 0.0: rows and key tiles are anchored at frame 0
+
+
+def test_flow_incremental_chunks_equal_full_recompute():
+    """FY_INCREMENTAL (csrc/flow.hip): a streaming chunk that extends the previous one pushes only its NEW rows through the DiT blocks,
+    against the keys / values kept per (Euler step, block).  With the reference's chunk schedule (25-token hops behind a prompt that
+    is a multiple of 25 tokens, 3 look-ahead tokens: every call ends on a boundary of the 50-frame chunk mask) the earlier rows
+    cannot see the new ones, so every chunk must equal the full recompute BIT FOR BIT (cli/model.py:339-369 recomputes; same values).
+    Also: a second stream after stream_reset; a call that does not end on a mask boundary (computed in full, still equal)."""
+    from fangyan_tts_amd.flow import FlowEngine
+    cfg = FlowCfg()
+    sd = synth.state_dict_torch(cfg.manifest(), DEV)
+    hop, look, p_tok, n_max = 25, cfg.pre_lookahead, 50, 4 * 25 + 3
+    eng = FlowEngine(sd, cfg, max_batch=1, max_frames=2 * (n_max + p_tok), device=DEV)
+    ref = FlowEngine(sd, cfg, max_batch=1, max_frames=2 * (n_max + p_tok), device=DEV)
+    noise = torch.from_numpy(synth.flow_rand_noise(2 * (n_max + p_tok)))
+    emb = torch.from_numpy(synth.normal("in.flow.spk", (1, cfg.spk_in)))
+    for stream in range(2):
+        token = torch.from_numpy(synth.randint(f"in.flow.token.inc{stream}", (1, n_max), 0, cfg.vocab))
+        ptoken = torch.from_numpy(synth.randint(f"in.flow.ptoken.inc{stream}", (1, p_tok), 0, cfg.vocab))
+        pfeat = torch.from_numpy(synth_mel(f"in.flow.pfeat.inc{stream}", 2 * p_tok))
+        eng.stream_reset()
+        for k in range(1, 5):
+            n_in = k * hop + look
+            args = (token[:, :n_in].contiguous(), [n_in], ptoken, [p_tok], pfeat, [2 * p_tok], emb, noise)
+            full = ref.inference(*args, streaming=True, finalize=False)
+            inc = eng.inference(*args, streaming=True, finalize=False, incremental=True)
+            valid = 2 * (n_in - look)
+            assert torch.equal(inc[:, :, :valid], full[:, :, :valid]), (stream, k, maxerr(inc[:, :, :valid], full[:, :, :valid]))
+    # a call that ends off the mask boundary is computed in full (and keeps nothing a later call could misuse)
+    n_in = 2 * hop + look + 4
+    args = (token[:, :n_in].contiguous(), [n_in], ptoken, [p_tok], pfeat, [2 * p_tok], emb, noise)
+    assert torch.equal(eng.inference(*args, streaming=True, finalize=False, incremental=True), ref.inference(*args, streaming=True, finalize=False))
+    n_in = 3 * hop + look
+    args = (token[:, :n_in].contiguous(), [n_in], ptoken, [p_tok], pfeat, [2 * p_tok], emb, noise)
+    assert torch.equal(eng.inference(*args, streaming=True, finalize=False, incremental=True), ref.inference(*args, streaming=True, finalize=False))
