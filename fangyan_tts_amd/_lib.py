@@ -94,6 +94,7 @@ def _declare(L):
     L.fy_flow_destroy.restype = None
     L.fy_flow_infer.argtypes = [vp, vp, i32, i32p, vp, i32, i32p, f32p, i32, i32p, f32p, f32p, i32, i32, f32p, i32, u32, vp]
     L.fy_flow_stream_reset.argtypes = [vp]
+    L.fy_flow_stream_rows.argtypes = [vp]
     L.fy_dit_estimator.argtypes = [vp, f32p, f32p, f32p, f32p, f32p, f32p, i32, i32, u32, vp]
     L.fy_llm_default_config.argtypes = [C.POINTER(LlmConfig)]
     L.fy_llm_default_config.restype = None

@@ -3,8 +3,10 @@
 
 // qkv: bf16 [nseq*Tmax][3*H*64] laid out [q | k | v]; out: bf16 [nseq*Tmax][H*64]; seq_len: device int[nseq].
 // chunk > 0 adds the streaming block-causal mask key < (query/chunk + 1)*chunk.  q_begin > 0: only the rows from q_begin on are
-// computed and written (the keys / values of the rows before them are read as they stand: incremental streaming).
-int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st, int q_begin = 0);
+// computed and written (the keys / values of the rows before them are read as they stand: incremental streaming).  interleaved:
+// row t of sequence s is row nseq * t + s of qkv / out instead of s * Tmax + t.
+int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st, int q_begin = 0,
+                  bool interleaved = false);
 
 // The split-operand form (fp32-class flow decoder): q, k, v and the output as x = hi + lo, two bf16 planes each, same layouts;
 // three MFMAs per product keep the hi x hi, hi x lo and lo x hi terms, softmax in fp32.

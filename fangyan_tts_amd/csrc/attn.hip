@@ -28,7 +28,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 // qkv: bf16 [nseq*Tmax][3*H*64] as [q | k | v]; out: bf16 [nseq*Tmax][H*64]
 template <int AT_NW, int WPE>
 __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void dit_attention_k(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                              const int* __restrict__ seq_len, int Tmax, int H, int chunk, float scale_log2, int q_begin) {
+                                                              const int* __restrict__ seq_len, int Tmax, int H, int chunk, float scale_log2, int q_begin, int seq_rows, int row_step) {
     __shared__ __attribute__((aligned(16))) bf16_t Kbuf[2][64 * AT_KP];      // two tiles: the next one is written while this one is read,
     __shared__ __attribute__((aligned(16))) bf16_t Vbuf[2][64 * AT_VP];      // one barrier per key tile
     // the many-wave form runs at 4 waves per SIMD (128 registers): the query fragments wait in LDS instead of 16 registers
@@ -39,14 +39,16 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE,
     const int len = seq_len[s];
     if (q0 >= len || q0 + AT_NW * 32 <= q_begin) return;     // q_begin: only the queries from that row on are wanted (incremental streaming)
     const int ld = 3 * H * AT_D;
-    const bf16_t* base = qkv + (long)s * Tmax * ld;
+    // row t of sequence s is row s * seq_rows + t * row_step of the tensors (s Tmax + t, or 2 t + s: the sequences interleaved)
+    const long ldr = (long)ld * row_step;
+    const bf16_t* base = qkv + (long)s * seq_rows * ld;
     const int lr = lane & 31, hf = lane >> 5;
     const int qrow = q0 + wid * 32 + lr;                     // this lane's query
     frag_ab qf[4];                                           // B[k = 16ks + 8hf + j][col = query]
     bf16_t* Qs = Qbuf + (QL ? (wid * 32 + lr) * AT_KP + hf * 8 : 0);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = *reinterpret_cast<const frag_ab*>(base + (long)min(qrow, len - 1) * ld + h * AT_D + ks * 16 + hf * 8);
+        qf[ks] = *reinterpret_cast<const frag_ab*>(base + (long)min(qrow, len - 1) * ldr + h * AT_D + ks * 16 + hf * 8);
         if (QL) *reinterpret_cast<frag_ab*>(Qs + ks * 16) = qf[ks];      // read back by the same lane only
     }
     f32x16 o[2];                                             // O^T[d = 32dt + (r&3) + 8(r>>2) + 4hf][query]
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE,
             const int c = tid + i * NT, idx = c & 511, key = idx >> 3, dc = (idx & 7) * 8;
             if (1024 % NT == 0 || c < 1024) {
                 const bool ok = k0 + key < len;
-                const bf16_t* p = base + (long)min(k0 + key, len - 1) * ld + h * AT_D + dc + (c < 512 ? 1 : 2) * H * AT_D;
+                const bf16_t* p = base + (long)min(k0 + key, len - 1) * ldr + h * AT_D + dc + (c < 512 ? 1 : 2) * H * AT_D;
                 kvreg[i] = *reinterpret_cast<const uint4*>(p);
                 if (!ok) kvreg[i] = make_uint4(0, 0, 0, 0);
             }
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE,
     }
     if (qrow >= len || qrow < q_begin) return;
     const float inv = 1.f / l_run;
-    bf16_t* op = out + ((long)s * Tmax + qrow) * (H * AT_D) + h * AT_D;
+    bf16_t* op = out + ((long)s * seq_rows + (long)qrow * row_step) * (H * AT_D) + h * AT_D;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE,
         }
 }
 
-int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st, int q_begin) {
+int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st, int q_begin, bool interleaved) {
     FY_CHECK(qkv && out && seq_len && nseq >= 1 && Tmax >= 1 && H >= 1, FY_ERR_ARG, "dit_attention: bad arguments");
     const float sl2 = 0.125f * 1.4426950408889634f;
     static int cus = 0;
@@ -213,15 +215,16 @@ int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, 
     // K/V are staged once per pair and the grid is a single round - 27.5 us (rocprofv3 over bench.py --no-pipeline).  From 8 waves
     // on the form needs no spill at 128 registers.
     const int nw = cdiv(Tmax, 32);
+    const int seq_rows = interleaved ? 1 : Tmax, row_step = interleaved ? nseq : 1;
     int W = 4;                                                   // waves per workgroup
     if (force) W = force;
     else if (nw >= 8 && nw <= 16 && H * nseq >= cus / 2 && q_begin == 0) W = nw;
     if (W <= 4) {
         dim3 grid(cdiv(Tmax, 4 * 32), H, nseq);
-        hipLaunchKernelGGL((dit_attention_k<4, 3>), grid, dim3(4 * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2, q_begin);
+        hipLaunchKernelGGL((dit_attention_k<4, 3>), grid, dim3(4 * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2, q_begin, seq_rows, row_step);
     } else {
         dim3 grid(cdiv(nw, W), H, nseq);
-#define FY_ATT_CASE(N) case N: hipLaunchKernelGGL((dit_attention_k<N, 4>), grid, dim3(N * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2, q_begin); break;
+#define FY_ATT_CASE(N) case N: hipLaunchKernelGGL((dit_attention_k<N, 4>), grid, dim3(N * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2, q_begin, seq_rows, row_step); break;
         switch (W) {
             FY_ATT_CASE(8) FY_ATT_CASE(9) FY_ATT_CASE(10) FY_ATT_CASE(11) FY_ATT_CASE(12)
             FY_ATT_CASE(13) FY_ATT_CASE(14) FY_ATT_CASE(15) FY_ATT_CASE(16)

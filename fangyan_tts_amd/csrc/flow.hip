@@ -106,7 +106,8 @@ __global__ void flow_setup_k(const float* __restrict__ mu_tok, const float* __re
 // InputEmbedding concat [x, cond, mu, spks] (dit.py:91-96) for the conditional row and [x, 0, 0, 0]
 // for the CFG row (flow_matching.py:95-101), as the bf16 A operand of the input projection.
 __global__ void dit_assemble_k(const float* __restrict__ x, const float* __restrict__ cond, const float* __restrict__ mu, const float* __restrict__ spks,
-                               const int* __restrict__ T, bf16_t* __restrict__ a, bf16_t* __restrict__ a_lo, int Tmax, int C) {
+                               const int* __restrict__ T, bf16_t* __restrict__ a, bf16_t* __restrict__ a_lo, int Tmax, int C, int seq_rows, int row_step) {
+    // output row of (sequence s, frame t): s * seq_rows + t * row_step (s Tmax + t; or 2 t + s - the incremental streaming layout)
     int s = blockIdx.y, t = blockIdx.x, b = s >> 1, cfg = s & 1;
     int i = threadIdx.x;                     // 0 .. 4C
     if (i >= 4 * C) return;
@@ -118,8 +119,9 @@ __global__ void dit_assemble_k(const float* __restrict__ x, const float* __restr
         else if (!cfg) v = part == 1 ? cond[o + c] : (part == 2 ? mu[o + c] : spks[(long)b * C + c]);
     }
     const bf16_t hb = f32_to_bf16(v);
-    a[((long)s * Tmax + t) * 4 * C + i] = hb;
-    if (a_lo) a_lo[((long)s * Tmax + t) * 4 * C + i] = f32_to_bf16(v - bf16_to_f32(hb));      // fp32-class mode (FY_PRECISE): x = hi + lo
+    const long orow = (long)s * seq_rows + (long)t * row_step;
+    a[orow * 4 * C + i] = hb;
+    if (a_lo) a_lo[orow * 4 * C + i] = f32_to_bf16(v - bf16_to_f32(hb));      // fp32-class mode (FY_PRECISE): x = hi + lo
 }
 
 // LayerNorm(eps 1e-6, no affine) * (1 + scale) + shift -> bf16 (modules.py:238-243, 524, 262-264). One wave per row.
@@ -189,10 +191,13 @@ __global__ __launch_bounds__(256) void ln_mod_k(const float* __restrict__ h, con
 }
 
 // CFG mix and Euler update, flow_matching.py:114-118
-__global__ void euler_k(float* __restrict__ x, const float* __restrict__ v, const int* __restrict__ T, int Tmax, int C, float dt, float cfg, int t0) {
+__global__ void euler_k(float* __restrict__ x, const float* __restrict__ v, const int* __restrict__ T, int Tmax, int C, float dt, float cfg, int t0,
+                        int interleaved) {
     int b = blockIdx.y, t = t0 + blockIdx.x, c = threadIdx.x;
     if (t >= T[b] || c >= C) return;
-    float vc = v[((long)(2 * b) * Tmax + t) * C + c], vu = v[((long)(2 * b + 1) * Tmax + t) * C + c];
+    // v rows: sequence s at s Tmax + t, or (incremental streaming, batch 1) the two sequences interleaved: 2 t + s
+    float vc = interleaved ? v[(2L * t) * C + c] : v[((long)(2 * b) * Tmax + t) * C + c];
+    float vu = interleaved ? v[(2L * t + 1) * C + c] : v[((long)(2 * b + 1) * Tmax + t) * C + c];
     float d = (1.0f + cfg) * vc - cfg * vu;
     long o = ((long)b * Tmax + t) * C + c;
     x[o] = x[o] + dt * d;
@@ -492,73 +497,69 @@ static int inc_alloc(fy_flow* f) {
     return FY_OK;
 }
 
-// The incremental form of dit_forward for a streaming chunk at batch 1 (two sequences: conditional and CFG branch): the input
-// projection and the causal position convs run over all T rows (cheap, and they need the rows to the left), then ONLY the rows
-// [T0, T) go through the blocks - per sequence, in place in the full-size buffers (row s Tmax + t) - while attention reads the
-// keys / values of the earlier rows from the (step, block) slice of inc_qkv, into which the qkv product of the new rows writes
-// directly.  Under the chunk mask with T0 and T on chunk boundaries the rows before T0 see nothing of the new ones, so their
-// keys, values and outputs are what the previous call computed: same bits as the full recompute (test).
-// Every buffer is addressed at the handle's CAPACITY pitch here (row s f->Tmax + t), so that a row keeps its place from call to call.
+// The incremental form of dit_forward for a streaming chunk at batch 1 (two sequences: conditional and CFG branch).  Layout: the
+// two sequences' rows INTERLEAVED - frame t of sequence s is row 2 t + s of every buffer - so the new frames [T0, T) of both
+// sequences are ONE contiguous run of rows and every product of a block stays one launch.  The input projection and the causal
+// position convs run over all T frames (cheap, and they need the frames to the left), then ONLY the rows [2 T0, 2 T) go through
+// the blocks, while attention reads the keys / values of the earlier frames from the (step, block) slice of inc_qkv, into which
+// the qkv product of the new rows writes directly.  Under the chunk mask with T0 and T on chunk boundaries the frames before T0
+// see nothing of the new ones, so their keys, values and outputs are what the previous call computed: same bits as the full
+// recompute (tests/test_stream_gpu.py).
 static int dit_forward_inc(fy_flow* f, int step, int T0, int T, hipStream_t st) {
     const fy_flow_config& c = f->cfg;
-    const int D = c.dim, C = c.mel, inner = c.heads * c.head_dim, FF = D * c.ff_mult, nseq = 2, Tc = T - T0, Tmax = f->Tmax;
-    const int M = nseq * Tmax;
+    const int D = c.dim, C = c.mel, inner = c.heads * c.head_dim, FF = D * c.ff_mult, nseq = 2, Mn = nseq * (T - T0);
+    const size_t r0 = (size_t)nseq * T0;                                       // first new row
     GemmEpi e;
     e.bias = f->b_in; e.out = f->h; e.out_bf16 = 0; e.ldc = D;
-    FY_TRY(gemm_bf16(f->a_in, 4 * C, f->w_in, M, D, 4 * C, e, st));
+    FY_TRY(gemm_bf16(f->a_in, 4 * C, f->w_in, nseq * T, D, 4 * C, e, st));
     {
         ConvDesc d;
         memset(&d, 0, sizeof(d));
         d.B = nseq; d.dil = 1; d.stride = 1; d.up = 1; d.groups = c.conv_pos_groups; d.out_scale = 1.f;
-        d.x = f->h; d.x_bs = (long)Tmax * D; d.x_ld = D; d.L_in = Tmax; d.in_len = f->seq_len;
-        d.y = f->c1; d.y_bs = (long)Tmax * D; d.y_ld = D; d.L_out = Tmax; d.out_len = f->seq_len;
+        d.x = f->h; d.x_bs = D; d.x_ld = nseq * D; d.L_in = T; d.in_len = f->seq_len;          // sequence s = every second row from row s
+        d.y = f->c1; d.y_bs = D; d.y_ld = nseq * D; d.L_out = T; d.out_len = f->seq_len;
         d.Cin = D; d.Cout = D; d.KW = c.conv_pos_k; d.pad_left = c.conv_pos_k - 1; d.bias = f->pos1.bias; d.post_act = ACT_MISH;
         const bool mf = f->pos1.w_mfma != nullptr;
         FY_TRY(mf ? conv1d_bf16_mfma(d, f->pos1, false, st) : conv1d_f32_direct(d, f->pos1, st));
         d.x = f->c1; d.y = f->h; d.bias = f->pos2.bias;
-        d.add_resid = 1; d.resid = f->h; d.r_bs = (long)Tmax * D; d.r_ld = D;
+        d.add_resid = 1; d.resid = f->h; d.r_bs = D; d.r_ld = nseq * D;
         FY_TRY(mf ? conv1d_bf16_mfma(d, f->pos2, false, st) : conv1d_f32_direct(d, f->pos2, st));
     }
     const float* modbase = f->mod + (size_t)step * c.depth * 6 * D;
-    const size_t slice = (size_t)nseq * f->Tmax * 3 * inner;                 // one (step, block) slice of inc_qkv, rows at the handle's Tmax pitch
+    const size_t slice = (size_t)nseq * f->Tmax * 3 * inner;                 // one (step, block) slice of inc_qkv
+    float* h = f->h + r0 * D;
+    bf16_t* xn = f->xn + r0 * D;
     for (int i = 0; i < c.depth; ++i) {
         const FlowBlockW& k = f->blk[i];
         const float* m = modbase + (size_t)i * 6 * D;
         bf16_t* qkv = f->inc_qkv + ((size_t)step * c.depth + i) * slice;
-        for (int s = 0; s < nseq; ++s) {
-            const size_t r0 = (size_t)s * Tmax + T0;
-            hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(Tc, 4)), dim3(256), 0, st, f->h + r0 * D, m + D, m, f->xn + r0 * D, (bf16_t*)nullptr, Tc, D);
-            GemmEpi q;
-            q.bias = k.bqkv; q.out = qkv + r0 * 3 * inner; q.out_bf16 = 1; q.ldc = 3 * inner;
-            q.rope = f->rope + (size_t)T0 * (c.head_dim / 2); q.rope_T = Tc; q.rope_half = c.head_dim / 2; q.rope_stride = inner;
-            FY_TRY(gemm_bf16(f->xn + r0 * D, D, k.wqkv, Tc, 3 * inner, D, q, st));
-        }
-        FY_TRY(dit_attention(qkv, f->ao, f->seq_len, nseq, Tmax, c.heads, c.static_chunk, st, T0));
-        for (int s = 0; s < nseq; ++s) {
-            const size_t r0 = (size_t)s * Tmax + T0;
-            GemmEpi o;
-            o.mode = EPI_GATE_RESID; o.bias = k.bo; o.resid = f->h + r0 * D; o.gate = m + 2 * D; o.ldc = D;
-            FY_TRY(gemm_bf16(f->ao + r0 * inner, inner, k.wo, Tc, D, inner, o, st));
-            hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(Tc, 4)), dim3(256), 0, st, f->h + r0 * D, m + 4 * D, m + 3 * D, f->xn + r0 * D, (bf16_t*)nullptr, Tc, D);
-            GemmEpi g;
-            g.bias = k.b1; g.act = ACT_GELU_TANH; g.out = f->ff + r0 * FF; g.out_bf16 = 1; g.ldc = FF;
-            FY_TRY(gemm_bf16(f->xn + r0 * D, D, k.w1, Tc, FF, D, g, st));
-            GemmEpi r;
-            r.mode = EPI_GATE_RESID; r.bias = k.b2; r.resid = f->h + r0 * D; r.gate = m + 5 * D; r.ldc = D;
-            FY_TRY(gemm_bf16(f->ff + r0 * FF, FF, k.w2, Tc, D, FF, r, st));
-        }
+        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(Mn, 4)), dim3(256), 0, st, h, m + D, m, xn, (bf16_t*)nullptr, Mn, D);
+        GemmEpi q;
+        q.bias = k.bqkv; q.out = qkv + r0 * 3 * inner; q.out_bf16 = 1; q.ldc = 3 * inner;
+        q.rope = f->rope + (size_t)T0 * (c.head_dim / 2); q.rope_T = T - T0; q.rope_div = nseq; q.rope_half = c.head_dim / 2; q.rope_stride = inner;
+        FY_TRY(gemm_bf16(xn, D, k.wqkv, Mn, 3 * inner, D, q, st));
+        FY_TRY(dit_attention(qkv, f->ao, f->seq_len, nseq, T, c.heads, c.static_chunk, st, T0, true));
+        GemmEpi o;
+        o.mode = EPI_GATE_RESID; o.bias = k.bo; o.resid = h; o.gate = m + 2 * D; o.ldc = D;
+        FY_TRY(gemm_bf16(f->ao + r0 * inner, inner, k.wo, Mn, D, inner, o, st));
+        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(Mn, 4)), dim3(256), 0, st, h, m + 4 * D, m + 3 * D, xn, (bf16_t*)nullptr, Mn, D);
+        GemmEpi g;
+        g.bias = k.b1; g.act = ACT_GELU_TANH; g.out = f->ff + r0 * FF; g.out_bf16 = 1; g.ldc = FF;
+        FY_TRY(gemm_bf16(xn, D, k.w1, Mn, FF, D, g, st));
+        GemmEpi r;
+        r.mode = EPI_GATE_RESID; r.bias = k.b2; r.resid = h; r.gate = m + 5 * D; r.ldc = D;
+        FY_TRY(gemm_bf16(f->ff + r0 * FF, FF, k.w2, Mn, D, FF, r, st));
     }
     const float* fn = f->fin + (size_t)step * 2 * D;
-    for (int s = 0; s < nseq; ++s) {
-        const size_t r0 = (size_t)s * Tmax + T0;
-        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(Tc, 4)), dim3(256), 0, st, f->h + r0 * D, fn, fn + D, f->xn + r0 * D, (bf16_t*)nullptr, Tc, D);
-        GemmEpi p;
-        p.bias = f->b_out; p.out = f->v + r0 * C; p.out_bf16 = 0; p.ldc = C;
-        FY_TRY(gemm_bf16(f->xn + r0 * D, D, f->w_out, Tc, C, D, p, st));
-    }
+    hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(Mn, 4)), dim3(256), 0, st, h, fn, fn + D, xn, (bf16_t*)nullptr, Mn, D);
+    GemmEpi p;
+    p.bias = f->b_out; p.out = f->v + r0 * C; p.out_bf16 = 0; p.ldc = C;
+    FY_TRY(gemm_bf16(xn, D, f->w_out, Mn, C, D, p, st));
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
+
+extern "C" int fy_flow_stream_rows(const fy_flow* f) { return f ? f->inc_T : -1; }
 
 extern "C" int fy_flow_stream_reset(fy_flow* f) {
     FY_CHECK(f, FY_ERR_ARG, "fy_flow_stream_reset: null handle");
@@ -631,9 +632,9 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
         for (int step = 0; step < c.n_timesteps; ++step) {
             // the state at this step: the earlier rows as the previous calls left them, the new rows as they evolve in f->x
             HIP_TRY(hipMemcpyAsync(xs + step * xslice + (size_t)T0 * C, f->x + (size_t)T0 * C, (size_t)(Tmax - T0) * C * sizeof(float), hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(dit_assemble_k, dim3(f->Tmax, 2), dim3(4 * C), 0, st, xs + step * xslice, f->cond, f->mu, f->spks, d_T, f->a_in, (bf16_t*)nullptr, f->Tmax, C);
+            hipLaunchKernelGGL(dit_assemble_k, dim3(Tmax, 2), dim3(4 * C), 0, st, xs + step * xslice, f->cond, f->mu, f->spks, d_T, f->a_in, (bf16_t*)nullptr, Tmax, C, 1, 2);
             FY_TRY(dit_forward_inc(f, step, T0, Tmax, st));
-            hipLaunchKernelGGL(euler_k, dim3(Tmax - T0, 1), dim3(128), 0, st, f->x, f->v, d_T, f->Tmax, C, f->dt_of_step[step], c.cfg_rate, T0);
+            hipLaunchKernelGGL(euler_k, dim3(Tmax - T0, 1), dim3(128), 0, st, f->x, f->v, d_T, Tmax, C, f->dt_of_step[step], c.cfg_rate, T0, 1);
         }
         HIP_TRY(hipMemcpyAsync(xs + c.n_timesteps * xslice + (size_t)T0 * C, f->x + (size_t)T0 * C, (size_t)(Tmax - T0) * C * sizeof(float), hipMemcpyDeviceToDevice, st));
         f->inc_T = Tmax;
@@ -645,9 +646,9 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
     if (flags & FY_INCREMENTAL) f->inc_T = 0;             // a call that could not be incremental breaks the stream
     for (int step = 0; step < c.n_timesteps; ++step) {
         hipLaunchKernelGGL(dit_assemble_k, dim3(Tmax, 2 * B), dim3(4 * C), 0, st, f->x, f->cond, f->mu, f->spks, d_T, f->a_in,
-                           (flags & FY_PRECISE) ? f->a_in_lo : nullptr, Tmax, C);
+                           (flags & FY_PRECISE) ? f->a_in_lo : nullptr, Tmax, C, Tmax, 1);
         FY_TRY(dit_forward(f, 2 * B, Tmax, step, (flags & FY_STREAMING) != 0, flags, st));
-        hipLaunchKernelGGL(euler_k, dim3(Tmax, B), dim3(128), 0, st, f->x, f->v, d_T, Tmax, C, f->dt_of_step[step], c.cfg_rate, 0);
+        hipLaunchKernelGGL(euler_k, dim3(Tmax, B), dim3(128), 0, st, f->x, f->v, d_T, Tmax, C, f->dt_of_step[step], c.cfg_rate, 0, 0);
     }
     // mel[b] = x[b][pmel:, :]^T in the reference's (B, 80, F) layout, flow.py:401
     for (int b = 0; b < B; ++b) {
@@ -719,7 +720,7 @@ extern "C" int fy_dit_estimator(fy_flow* f, float* x, const float* mask, const f
         for (int s = 0; s < B2; ++s) {
             hipLaunchKernelGGL(dit_assemble_k, dim3(T, 1), dim3(4 * C), 0, st, sx + (size_t)s * T * C, sc + (size_t)s * T * C,
                                sm + (size_t)s * T * C, spks + (size_t)s * C, f->seq_len + s, f->a_in + (size_t)s * T * 4 * C,
-                               (flags & FY_PRECISE) ? f->a_in_lo + (size_t)s * T * 4 * C : nullptr, T, C);
+                               (flags & FY_PRECISE) ? f->a_in_lo + (size_t)s * T * 4 * C : nullptr, T, C, T, 1);
         }
     }
     // a_in was written by rows of T (not f->Tmax): run the estimator with Tmax = T; h is overwritten only after a_in is complete

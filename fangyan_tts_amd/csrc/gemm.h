@@ -24,6 +24,7 @@ struct GemmEpi {
     // [rope_stride, rope_stride + 2*rope_half) at position (row % rope_T), table [rope_T][rope_half] of (cos, sin)
     const float2* rope = nullptr;
     int rope_T = 0, rope_half = 0, rope_stride = 0;
+    int rope_div = 1;                  // position of output row m = (m / rope_div) % rope_T (2: the two sequences' rows interleaved)
     // split-operand (fp32-class) products, gemm_split: the A operand arrives as TWO bf16 planes, x = hi + lo with hi = bf16(x) and
     // lo = bf16(x - hi) - a_lo is the lo plane ([M][lda] like A); out_lo != null stores the result the same way (out = hi plane,
     // out_lo = lo plane, both bf16 [M][ldc]) for the next product, after the exact-tanh GELU (act) or the rotary embedding (rope)

@@ -49,7 +49,7 @@ __device__ __forceinline__ void split8_3(const float4& a, const float4& b, uint4
 __device__ __forceinline__ void epi_rope(float4& v, const GemmEpi& e, int m, int n) {
     int nn = n >= e.rope_stride ? n - e.rope_stride : n;
     if (n >= 2 * e.rope_stride || nn >= 2 * e.rope_half) return;
-    const float2* tab = e.rope + (long)(m % e.rope_T) * e.rope_half + (nn >> 1);
+    const float2* tab = e.rope + (long)((m / e.rope_div) % e.rope_T) * e.rope_half + (nn >> 1);
     const float2 c0 = tab[0], c1 = tab[1];
     const float a = v.x, b = v.y, c = v.z, d = v.w;
     v.x = a * c0.x - b * c0.y; v.y = b * c0.x + a * c0.y;
@@ -511,7 +511,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
         const int m00 = m0 + wm * (MI * 32) + mi * 32 + rsub;
 #pragma unroll
         for (int it = 0; it < 8; ++it)
-            t[it] = *reinterpret_cast<const float4*>(e.rope + (long)(min(m00 + it * 4, M - 1) % e.rope_T) * e.rope_half + rope_col);
+            t[it] = *reinterpret_cast<const float4*>(e.rope + (long)((min(m00 + it * 4, M - 1) / e.rope_div) % e.rope_T) * e.rope_half + rope_col);
     };
     if (RE && RAHEAD) rope_fetch(0, rt);
 #pragma unroll
@@ -696,7 +696,7 @@ static int gemm_check(const void* A, int lda, const bf16_t* W, int M, int N, int
     FY_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && (lda * a_elem) % 16 == 0, FY_ERR_ARG, "gemm: operands must be 16-B aligned");
     FY_CHECK(e.ldc >= N && ((e.mode == EPI_STORE && e.out) || (e.mode == EPI_GATE_RESID && e.resid && e.gate)), FY_ERR_ARG, "gemm: bad epilogue");
     FY_CHECK(N % 4 == 0 && e.ldc % 4 == 0, FY_ERR_ARG, "gemm: N and the output pitch must be multiples of 4 (N %d, ldc %d)", N, e.ldc);
-    FY_CHECK(!e.rope || (e.mode == EPI_STORE && e.act == ACT_NONE && e.rope_T >= 1 && e.rope_half >= 2 && e.rope_half % 2 == 0 &&
+    FY_CHECK(!e.rope || (e.mode == EPI_STORE && e.act == ACT_NONE && e.rope_T >= 1 && e.rope_div >= 1 && e.rope_half >= 2 && e.rope_half % 2 == 0 &&
                          e.rope_stride >= 2 * e.rope_half), FY_ERR_ARG, "gemm: bad rotary epilogue");
     return FY_OK;
 }

@@ -102,6 +102,10 @@ class FlowEngine:
         """Forget what incremental calls have kept: the next one starts a new stream."""
         check(_lib.lib().fy_flow_stream_reset(self._h))
 
+    def stream_rows(self) -> int:
+        """Mel rows the incremental calls of the current stream have kept (0: the next call computes everything)."""
+        return int(_lib.lib().fy_flow_stream_rows(self._h))
+
     def speed(self, mel: torch.Tensor, speed: float) -> torch.Tensor:
         """cli/model.py:435-437: F.interpolate(mel, size=int(F / speed), mode="linear") on (B, 80, F)."""
         mel = mel.to(self.device, torch.float32).contiguous()

@@ -141,6 +141,8 @@ int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, const int32_
 
 /* forget what FY_INCREMENTAL calls have kept: the next one starts a new stream (call it when a stream=True generation begins) */
 int fy_flow_stream_reset(fy_flow* f);
+/* mel rows (prompt + generated frames) the incremental calls of the current stream have kept; 0 = nothing (the next call computes all) */
+int fy_flow_stream_rows(const fy_flow* f);
 
 /* replaces the estimator hand-off ConditionalCFM.forward_estimator uses for a non-nn.Module estimator
  *   cosyvoice/flow/flow_matching.py:126-153: contiguous x (B2,80,T), mask (B2,1,T), mu (B2,80,T), t (B2),

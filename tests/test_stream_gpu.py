@@ -209,10 +209,12 @@ def test_flow_incremental_chunks_equal_full_recompute():
             inc = eng.inference(*args, streaming=True, finalize=False, incremental=True)
             valid = 2 * (n_in - look)
             assert torch.equal(inc[:, :, :valid], full[:, :, :valid]), (stream, k, maxerr(inc[:, :, :valid], full[:, :, :valid]))
+            assert eng.stream_rows() == 2 * (p_tok + n_in - look)            # the call really was incremental: its rows are kept
     # a call that ends off the mask boundary is computed in full (and keeps nothing a later call could misuse)
     n_in = 2 * hop + look + 4
     args = (token[:, :n_in].contiguous(), [n_in], ptoken, [p_tok], pfeat, [2 * p_tok], emb, noise)
     assert torch.equal(eng.inference(*args, streaming=True, finalize=False, incremental=True), ref.inference(*args, streaming=True, finalize=False))
+    assert eng.stream_rows() == 0
     n_in = 3 * hop + look
     args = (token[:, :n_in].contiguous(), [n_in], ptoken, [p_tok], pfeat, [2 * p_tok], emb, noise)
     assert torch.equal(eng.inference(*args, streaming=True, finalize=False, incremental=True), ref.inference(*args, streaming=True, finalize=False))
