@@ -259,6 +259,12 @@ void gemm_set_stamps(unsigned long long* p) { hipMemcpyToSymbol(HIP_SYMBOL(gemm_
 #else
 #define G2_STAMP(i) do { } while (0)
 #endif
+#ifndef G2_INTERLEAVE
+#define G2_INTERLEAVE 1
+#endif
+#ifndef G2_DIRECT
+#define G2_DIRECT 1
+#endif
 #define G2_RING_BYTES (96 * 1024)                            // BN 256: three 32 KB stages; BN 128: three 24 KB stages = 72 KB, so that two workgroups share a CU
 
 // BN = 256: 8 waves as 2 (M) x 4 (N), 128x64 (BM 256) or 160x64 (BM 320) per wave.  BN = 128: 4 x 2 waves of 64x64, <= 128 VGPRs
@@ -278,6 +284,13 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     constexpr int WN = BN / 64, WM = NWAVE / WN, MI = BM / WM / 32;       // waves along N / M, 32-row tiles per wave
     static_assert(!SP || (MF && !STAG), "the split-operand form exists for the 16x16x32 products without staggered wave groups");
     constexpr int APL = SP ? 2 : 1;                                       // A planes per stage
+    // DE: the direct epilogue of the 16x16x32 form (at the end of the kernel).  The products are taken TRANSPOSED - the W fragment
+    // as the instruction's first operand - so a lane ends up with one output row's values, and W rows are dealt to the four
+    // column tiles j as local column (c >> 2) * 16 + 4 j + (c & 3) for instruction index c, so those values are 16 CONSECUTIVE
+    // columns: stored from the registers in full 128-byte lines, no trip through LDS.  Same products, same K order: same bits.
+    // Its B fragment reads 4 rows out of every 16, so rows 16 apart must sit in different slots: the swizzle gets a (row >> 4) term.
+    constexpr bool DE = MF && G2_DIRECT && EPI != 2 && EPI != 3;      // fp32 outputs (64-byte runs per row from here) stay on the LDS epilogue's full lines: out-proj 24 -> 32 us with this one
+    auto SW = [](int row) -> int { return DE ? (G2_SW(row) ^ ((0 - (row >> 4)) & 3)) : G2_SW(row); };
     constexpr int STAGE = (APL * BM + BN) * G2_BK * 2, STAGES = 3, NB = BN / (NWAVE * 16);   // NB: B DMAs per wave and stage
     constexpr int NA_ALL = APL * BM / 16, NA = (NA_ALL + NWAVE - 1) / NWAVE, NA_LAST = NA_ALL - (NA - 1) * NWAVE;   // A DMAs: wave-instruction j = i * NWAVE + wid fills rows [16 j, 16 j + 16) (SP: of plane j / (BM / 16)); the last round only on waves < NA_LAST
     constexpr int BOFF = APL * BM * G2_BK * 2;                            // the B tile follows the A tile(s) inside a stage
@@ -297,15 +310,25 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int j = i * NWAVE + wid;
-        const int row = (SP ? j % (BM / 16) : j) * 16 + (lane >> 2), c = (lane & 3) ^ G2_SW(row);
+        const int row = (SP ? j % (BM / 16) : j) * 16 + (lane >> 2), c = (lane & 3) ^ SW(row);
         const bf16_t* Ap = (SP && j >= BM / 16) ? e.a_lo : A;          // wave-uniform
         a_src[i] = Ap + (long)min(m0 + row, M - 1) * lda + c * 8;
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int row = (wid * NB + i) * 16 + (lane >> 2), c = (lane & 3) ^ G2_SW(row);
+        const int row = (wid * NB + i) * 16 + (lane >> 2), c = (lane & 3) ^ SW(row);
         b_src[i] = W + (long)min(n0 + row, N - 1) * K + c * 8;
     }
+    // DMA d of a stage (0 .. NA-1: A rows, NA .. NA+NB-1: B rows) on its own: the K loop of the 16x16x32 form issues a stage's DMAs
+    // one at a time between its MFMA groups (below)
+    auto issue_one = [&](int t, int d) {
+        char* st = smem + (t % STAGES) * STAGE;
+        if (d < NA) {
+            if (d + 1 < NA || a_last)
+                __builtin_amdgcn_global_load_lds((const void*)(a_src[d] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + (d * NWAVE + wid) * 1024), 16, 0, 0);
+        } else
+            __builtin_amdgcn_global_load_lds((const void*)(b_src[d - NA] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + BOFF + wid * NB * 1024 + (d - NA) * 1024), 16, 0, 0);
+    };
     auto issue = [&](int t) {
         char* st = smem + (t % STAGES) * STAGE;
 #pragma unroll
@@ -336,9 +359,12 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     f32x4 acc4[MF ? 2 * MI : 1][4];
     if constexpr (MF) {
 #pragma unroll
-        for (int i = 0; i < 2 * MI; ++i) { const int ra = wm * (MI * 32) + i * 16 + (lane & 15); a16[i] = ra * 64 + (((lane >> 4) ^ G2_SW(ra)) << 4); }
+        for (int i = 0; i < 2 * MI; ++i) { const int ra = wm * (MI * 32) + i * 16 + (lane & 15); a16[i] = ra * 64 + (((lane >> 4) ^ SW(ra)) << 4); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int rb = wn * 64 + i * 16 + (lane & 15); b16[i] = BOFF + rb * 64 + (((lane >> 4) ^ G2_SW(rb)) << 4); }
+        for (int i = 0; i < 4; ++i) {
+            const int rb = wn * 64 + (DE ? ((lane & 15) >> 2) * 16 + i * 4 + (lane & 3) : i * 16 + (lane & 15));
+            b16[i] = BOFF + rb * 64 + (((lane >> 4) ^ SW(rb)) << 4);
+        }
 #pragma unroll
         for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
@@ -383,22 +409,41 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): the slot may be refilled after the next barrier
         };
-        auto mfmas = [&]() {
+        // it >= 0: stage `it` is requested during the MFMA interval, one DMA after every few MFMAs - a DMA's issue waits for the
+        // CU's address path, and in the read interval (five in a row, beside 14 fragment reads) that wait was the interval
+        auto mfmas = [&](int it) {
+            constexpr int NM = MF ? 2 * MI * 4 : 2 * MI * 2, EV = NM / (D + 1);      // MFMAs of the interval; one DMA after every EV of them
+            int q = 0;
             __builtin_amdgcn_s_setprio(1);
+            auto between = [&]() {
+                ++q;
+                if constexpr (G2_INTERLEAVE) {
+                    if (q % EV == 0 && q / EV - 1 < D) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (it >= 0) issue_one(it, q / EV - 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
             if constexpr (MF) {
 #pragma unroll
                 for (int i = 0; i < 2 * MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i & 1][i >> 1], fb[j >> 1][j & 1], acc4[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        acc4[i][j] = DE ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j >> 1][j & 1], fa[i & 1][i >> 1], acc4[i][j], 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i & 1][i >> 1], fb[j >> 1][j & 1], acc4[i][j], 0, 0, 0);
+                        between();
+                    }
             } else
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
+                    for (int ni = 0; ni < 2; ++ni) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mi], fb[ks][ni], acc[mi][ni], 0, 0, 0);
+                        between();
+                    }
             __builtin_amdgcn_s_setprio(0);
         };
         wait_stage(0);
@@ -406,11 +451,11 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
         G2_STAMP(1);
         if (wid < NWAVE / 2) {
             for (int t = 0; t < nt; ++t) {
-                if (t + 2 < nt) issue(t + 2);
+                if (!G2_INTERLEAVE && t + 2 < nt) issue(t + 2);
                 reads(t);
                 __builtin_amdgcn_s_barrier();                       // 2t
                 __builtin_amdgcn_sched_barrier(0);
-                mfmas();
+                mfmas(G2_INTERLEAVE && t + 2 < nt ? t + 2 : -1);
                 wait_stage(t + 1);
                 __builtin_amdgcn_s_barrier();                       // 2t + 1
                 __builtin_amdgcn_sched_barrier(0);
@@ -424,8 +469,8 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
                 wait_stage(t + 1);
                 __builtin_amdgcn_s_barrier();                       // 2t + 1
                 __builtin_amdgcn_sched_barrier(0);
-                if (t + 3 < nt) issue(t + 3);
-                mfmas();
+                if (!G2_INTERLEAVE && t + 3 < nt) issue(t + 3);
+                mfmas(G2_INTERLEAVE && t + 3 < nt ? t + 3 : -1);
                 __builtin_amdgcn_s_barrier();                       // 2t + 2
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -440,10 +485,14 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
         else { if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (D - 1))); else __builtin_amdgcn_s_waitcnt(0x0F70 | (D - 1)); }
         __builtin_amdgcn_s_barrier();                               // everyone's part of stage t is in LDS; the slot of stage t-1 is free
         if (t == 0) G2_STAMP(1);
-        if (t + STAGES - 1 < nt) issue(t + STAGES - 1);
+        const bool refill = t + STAGES - 1 < nt;
+        if (!(MF && G2_INTERLEAVE) && refill) issue(t + STAGES - 1);
         const char* sb = smem + (t % STAGES) * STAGE;
         frag_ab fa[2][MI], fb[2][2];
         if constexpr (MF) {
+            // The refill of the slot freed by the barrier goes out one DMA at a time BETWEEN the MFMA groups, after this stage's
+            // fragment reads: a DMA's issue waits for the CU's one address path (1 KB at <= 64 B per clock, shared by every wave of
+            // the CU), and issued as a burst after the barrier - every wave of the workgroup in step - nothing computes meanwhile.
             frag_ab fl[SP ? 2 : 1][SP ? MI : 1];
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j >> 1][j & 1] = *reinterpret_cast<const frag_ab*>(sb + b16[j]);
@@ -453,17 +502,25 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
 #pragma unroll
                 for (int i = 0; i < 2 * MI; ++i) fl[i & 1][i >> 1] = *reinterpret_cast<const frag_ab*>(sb + a16[i] + BM * G2_BK * 2);
             }
+            constexpr int GR = (SP ? 2 : 1) * 2 * MI, ND = NA + NB;      // MFMA groups (four products each) and DMAs per stage
 #pragma unroll
-            for (int i = 0; i < 2 * MI; ++i)
+            for (int g = 0; g < GR; ++g) {
+                const int i = g % (2 * MI);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i & 1][i >> 1], fb[j >> 1][j & 1], acc4[i][j], 0, 0, 0);
-            if constexpr (SP) {
+                for (int j = 0; j < 4; ++j) {
+                    const frag_ab fx = g < 2 * MI ? fa[i & 1][i >> 1] : fl[i & 1][i >> 1];
+                    acc4[i][j] = DE ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j >> 1][j & 1], fx, acc4[i][j], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fb[j >> 1][j & 1], acc4[i][j], 0, 0, 0);
+                }
+                if constexpr (G2_INTERLEAVE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (refill) {
 #pragma unroll
-                for (int i = 0; i < 2 * MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[i & 1][i >> 1], fb[j >> 1][j & 1], acc4[i][j], 0, 0, 0);
+                        for (int d = 0; d < ND; ++d)
+                            if (d * GR / ND == g) issue_one(t + STAGES - 1, d);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             continue;
         }
@@ -487,6 +544,93 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     __syncthreads();                                                // all waves are done with the ring: the epilogue parks tiles in it
     G2_STAMP(2);
 
+    constexpr bool RE = EPI == 0 || EPI == 4;                       // epilogues that may carry the rotary embedding
+    if constexpr (DE) {
+        // Direct epilogue: for 16-row tile i the lane holds row (lane & 15), columns nq .. nq + 15 as acc4[i][j][r] = column 4 j + r.
+        // The residual rows (EPI 3) or the rotary table rows (RE) of tile i + 1 are fetched before tile i is stored.
+        const int nq = n0 + wn * 64 + (lane >> 4) * 16, mw = m0 + wm * (MI * 32) + (lane & 15);
+        float4 bq[4], gq[EPI == 3 ? 4 : 1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bq[c] = e.bias ? *reinterpret_cast<const float4*>(e.bias + nq + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (EPI == 3) gq[c] = *reinterpret_cast<const float4*>(e.gate + nq + 4 * c);
+        }
+        int rope_c = -1;                                            // float2 index of the lane's first pair inside a table row
+        if (RE && e.rope) {
+            const int nn = nq >= e.rope_stride ? nq - e.rope_stride : nq;
+            if (nq < 2 * e.rope_stride && nn < 2 * e.rope_half) rope_c = nn >> 1;
+        }
+        constexpr bool PF = EPI == 3 || RE, AHEAD = BN == 256;      // the one-per-CU tiles have the registers to fetch a tile ahead, and nobody else to hide the trip
+        float4 cur[PF ? 4 : 1], nxt[PF && AHEAD ? 4 : 1];
+        auto fetch = [&](int i, auto& t) {
+            const int m = min(mw + i * 16, M - 1);
+            if constexpr (EPI == 3) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[c] = *reinterpret_cast<const float4*>(e.resid + (long)m * e.ldc + nq + 4 * c);
+            } else if constexpr (RE) {
+                if (rope_c >= 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[c] = *reinterpret_cast<const float4*>(e.rope + (long)((m / e.rope_div) % e.rope_T) * e.rope_half + rope_c + 2 * c);
+                }
+            }
+        };
+        if constexpr (PF && AHEAD) fetch(0, cur);
+#pragma unroll
+        for (int i = 0; i < 2 * MI; ++i) {
+            if constexpr (PF && AHEAD) { if (i + 1 < 2 * MI) fetch(i + 1, nxt); }
+            if constexpr (PF && !AHEAD) fetch(i, cur);
+            const int m = mw + i * 16;
+            if (m < M) {
+                uint32_t pk[8], pl[8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float4 v = make_float4(acc4[i][c][0], acc4[i][c][1], acc4[i][c][2], acc4[i][c][3]);
+                    v.x += bq[c].x; v.y += bq[c].y; v.z += bq[c].z; v.w += bq[c].w;
+                    if constexpr (EPI == 3) {
+                        float4 o = cur[c];
+                        o.x = fmaf(gq[c].x, v.x, o.x); o.y = fmaf(gq[c].y, v.y, o.y); o.z = fmaf(gq[c].z, v.z, o.z); o.w = fmaf(gq[c].w, v.w, o.w);
+                        *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + nq + 4 * c) = o;
+                    } else if constexpr (EPI == 2) {
+                        *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + nq + 4 * c) = v;
+                    } else {
+                        if (EPI == 5) { v.x = act_gelu_tanh(v.x); v.y = act_gelu_tanh(v.y); v.z = act_gelu_tanh(v.z); v.w = act_gelu_tanh(v.w); }
+                        if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
+                        if constexpr (RE) {
+                            if (rope_c >= 0) {                       // x-transformers apply_rotary_pos_emb on two interleaved pairs (epi_rope's arithmetic)
+                                const float4 t = cur[c];
+                                const float a = v.x, b = v.y, cc = v.z, d = v.w;
+                                v.x = a * t.x - b * t.y; v.y = b * t.x + a * t.y;
+                                v.z = cc * t.z - d * t.w; v.w = d * t.z + cc * t.w;
+                            }
+                        }
+                        const bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
+                        pk[2 * c] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                        pk[2 * c + 1] = (uint32_t)h2 | ((uint32_t)h3 << 16);
+                        if constexpr (EPI == 4 || EPI == 5) {        // x = hi + lo as two bf16 planes for the next split-operand product
+                            pl[2 * c] = (uint32_t)f32_to_bf16(v.x - bf16_to_f32(h0)) | ((uint32_t)f32_to_bf16(v.y - bf16_to_f32(h1)) << 16);
+                            pl[2 * c + 1] = (uint32_t)f32_to_bf16(v.z - bf16_to_f32(h2)) | ((uint32_t)f32_to_bf16(v.w - bf16_to_f32(h3)) << 16);
+                        }
+                    }
+                }
+                if constexpr (EPI != 3 && EPI != 2) {
+                    bf16_t* o = (bf16_t*)e.out + (long)m * e.ldc + nq;
+                    *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    *reinterpret_cast<uint4*>(o + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                    if constexpr (EPI == 4 || EPI == 5) {
+                        bf16_t* ol = (bf16_t*)e.out_lo + (long)m * e.ldc + nq;
+                        *reinterpret_cast<uint4*>(ol) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                        *reinterpret_cast<uint4*>(ol + 8) = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+                    }
+                }
+            }
+            if constexpr (PF && AHEAD) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
+            }
+        }
+        G2_STAMP(3);
+        return;
+    }
     // epilogue through LDS, a quarter of the wave's tile (32 rows x 64 columns) at a time: see gemm_epilogue
     float* park = reinterpret_cast<float*>(smem) + wid * 32 * 68;
     const int c4 = (lane & 15) * 4, rsub = lane >> 4;
@@ -498,7 +642,6 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     // a 32-row block's eight table rows in one batch, one block AHEAD of their use (under the previous block's stores) - fetched
     // where they are used, each row's 16 bytes cost a trip to L2 in the middle of the store loop (qkv at M = 6400: +11 us on the
     // 320x256 tile, whose epilogue nothing hides).
-    constexpr bool RE = EPI == 0 || EPI == 4;                       // epilogues that may carry the rotary embedding
     int rope_col = -1;                                              // float2 index of this lane's first pair inside a table row
     if (RE && e.rope) {
         const int nn = n >= e.rope_stride ? n - e.rope_stride : n;
@@ -651,7 +794,10 @@ static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, i
     //   256x256 (1), plain / staggered      72.9 / 70.1  38.3 / 36.4  45.1 / 42.2  62.6 / 58.8   300 tiles: two rounds
     //   320x256 (1), staggered                 47.5         44.0         49.1         70.1       240 tiles: one round
     // All tilings give bit-identical outputs (K is accumulated in the same order; checked by gemm_bench).
-    if (!PRECISE && gemm_tile_override != 128 && N % 128 == 0 && K % G2_BK == 0) {
+    // the ring kernels' direct epilogue stores 16 consecutive columns per lane in 16-byte pieces
+    const bool ring_ok = (((uintptr_t)epi.out | (uintptr_t)epi.out_lo | (uintptr_t)epi.resid) & 15) == 0 && epi.ldc % 8 == 0 &&
+                         (!epi.rope || (epi.rope_half % 8 == 0 && epi.rope_stride % 16 == 0));
+    if (!PRECISE && gemm_tile_override != 128 && N % 128 == 0 && K % G2_BK == 0 && ring_ok) {
         static int cus = 0;
         if (!cus) {
             int dev = 0;
@@ -664,11 +810,15 @@ static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, i
         if (ov == 256 && N % 256 == 0) return gemm_launch_256<EPI, 256>(Ab, lda, W, M, N, K, epi, st);
         if (ov == 320 && N % 256 == 0) return gemm_launch_256<EPI, 256, 320>(Ab, lda, W, M, N, K, epi, st);
         if (ov == 1256 && N % 256 == 0) return gemm_launch_256<EPI, 256, 256, 1>(Ab, lda, W, M, N, K, epi, st);
+        if (ov == 3320 && N % 256 == 0) return gemm_launch_256<EPI, 256, 320, 1, 1>(Ab, lda, W, M, N, K, epi, st);
+        if (ov == 3256 && N % 256 == 0) return gemm_launch_256<EPI, 256, 256, 1, 1>(Ab, lda, W, M, N, K, epi, st);
+        if (ov == 2256 && N % 256 == 0) return gemm_launch_256<EPI, 256, 256, 0, 1>(Ab, lda, W, M, N, K, epi, st);
         if (ov == 2) return gemm_launch_256<EPI, 128>(Ab, lda, W, M, N, K, epi, st);
         if (ov == 3) return gemm_launch_256<EPI, 128, 128>(Ab, lda, W, M, N, K, epi, st);
         const int t128 = (N / 128) * cdiv(M, 256), t64 = (N / 128) * cdiv(M, 128), t320 = N % 256 ? 0 : (N / 256) * cdiv(M, 320);
         // 320x256 tiles, one workgroup per CU, when they cover the chip in ONE round where 256x128 tiles would need a second one
-        if ((ov == 1320 && N % 256 == 0) || (ov == 0 && t128 > 2 * cus && t320 <= cus && 20 * t320 >= 17 * cus)) return gemm_launch_256<EPI, 256, 320, 1>(Ab, lda, W, M, N, K, epi, st);
+        if (ov == 1320 && N % 256 == 0) return gemm_launch_256<EPI, 256, 320, 1>(Ab, lda, W, M, N, K, epi, st);
+        if (ov == 0 && t128 > 2 * cus && t320 <= cus && 20 * t320 >= 17 * cus) return gemm_launch_256<EPI, 256, 320, 1, 1>(Ab, lda, W, M, N, K, epi, st);
         // 256x128 tiles (two workgroups per CU: one's prologue / epilogue bursts run under the other's K loop) from one tile per CU on
         if (ov == 2002 || (ov == 0 && t128 >= cus)) return gemm_launch_256<EPI, 128, 256, 0, 1>(Ab, lda, W, M, N, K, epi, st);
         // fewer tiles than that: 128x128 tiles (4 waves, 48 KB, three workgroups per CU); the 16x16x32 form reads a K step's
