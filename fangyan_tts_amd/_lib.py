@@ -75,6 +75,7 @@ def _declare(L):
     L.fy_prof_enable.restype = None
     L.fy_prof_reset.restype = None
     L.fy_prof_get.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.fy_prof_union.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
     L.fy_llm_set_sampler.argtypes = [vp, i32, f32p, C.c_int64, i32, C.c_float, i32, C.c_float]
     L.fy_hift_default_config.argtypes = [C.POINTER(HiftConfig)]
     L.fy_hift_default_config.restype = None
@@ -152,6 +153,13 @@ def tensor_table(weights):
 
 def int_array(values):
     return (C.c_int32 * len(values))(*[int(v) for v in values])
+
+
+def prof_union(name: str) -> float:
+    """Milliseconds during which at least one profiled launch called `name` was running."""
+    ms = C.c_double()
+    check(lib().fy_prof_union(name.encode(), C.byref(ms)))
+    return ms.value
 
 
 def prof_get(name: str):

@@ -89,6 +89,7 @@ int transpose_blc_to_bcl(const float* src, float* dst, int B, int C, int L, long
 }
 
 // ---------------------------------------------------------------------------------------------
+#include <algorithm>
 #include <map>
 #include <mutex>
 struct ProfRec { std::string name; double work; hipEvent_t a, b; };
@@ -138,6 +139,32 @@ extern "C" int fy_prof_get(const char* name, double* total_ms, double* work, int
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
         *total_ms += ms; *work += r.work; *count += 1;
+    }
+    return FY_OK;
+}
+
+// The time during which AT LEAST ONE recorded launch called `name` was running: with the flow decoders of two steps side by side
+// (tts_pipeline, flow_workers = 2) two launches share the chip and each one's own duration says little about the chip's rate.
+extern "C" int fy_prof_union(const char* name, double* union_ms) {
+    FY_CHECK(name && union_ms, FY_ERR_ARG, "fy_prof_union: null argument");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    *union_ms = 0;
+    std::vector<std::pair<double, double>> iv;
+    const ProfRec* base = nullptr;
+    for (auto& r : g_prof) {
+        if (r.name != name) continue;
+        HIP_TRY(hipEventSynchronize(r.b));
+        if (!base) base = &r;
+        float t0 = 0.f, t1 = 0.f;
+        if (&r != base) HIP_TRY(hipEventElapsedTime(&t0, base->a, r.a));      // negative when r began before the first record (another stream)
+        HIP_TRY(hipEventElapsedTime(&t1, base->a, r.b));
+        iv.emplace_back((double)t0, (double)t1);
+    }
+    std::sort(iv.begin(), iv.end());
+    double end = -1e300;
+    for (auto& v : iv) {
+        if (v.first > end) { *union_ms += v.second - v.first; end = v.second; }
+        else if (v.second > end) { *union_ms += v.second - end; end = v.second; }
     }
     return FY_OK;
 }

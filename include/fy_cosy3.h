@@ -40,6 +40,7 @@ void fy_prof_enable(int on);
 void fy_prof_only(const char* name);   /* record only launches of this name (null: all) - keeps the cost off the other streams */
 void fy_prof_reset(void);
 int fy_prof_get(const char* name, double* total_ms, double* work, int64_t* count);
+int fy_prof_union(const char* name, double* union_ms);   /* time during which at least one recorded launch of this name was running (launches on several streams overlap) */
 
 /* Which of `n` HIP streams can run side by side: ratio (host fp32, n x n) receives, per pair, the time two concurrent
  * chains of short dependent kernels take over the time of one chain - ~1 when the two streams are served by different
