@@ -18,12 +18,14 @@ utterance (3 s of audio each), random-init weights of the CosyVoice3-0.5B archit
 (fangyan_tts_amd.synth), bf16 MFMA arithmetic for DiT / HiFT, fp32 activations in the LM.
 
 Consecutive steps are software-pipelined (defaults: 40 timed steps, 4 warm-up): ONE speech-token LM call decodes the batches of
-4 consecutive steps together (32 sequences per weight pass, csrc/gemv32.hip) beside the flow decoder + vocoder of the steps
-before; every step still runs the whole path on its own batch of 8 inside the timed region, and the record says what is in flight
-(`config`) and gives the strict one-batch-at-a-time figure beside the headline (`value_batch8_unpipelined`).  `roofline` is the
-kernel family with the largest GPU-time share of the timed region (the DiT linears), measured in the timed configuration with HIP
-events on the launch stream; `roofline_lm` the LM's decode products; every `traffic` comes from `rocprofv3 --pmc` over this very
-program (profiles/r03_bench_pmc.json; tests/micro/prof_r03.sh).  Secondary objects: `precise_mode`, `latency_b1`, `first_chunk`,
+4 consecutive steps together (32 sequences per weight pass, one persistent launch per token step: csrc/llm_decode32.hip) beside
+the flow decoders + vocoders of the steps before, two of which run side by side (--flow-workers 2); every step still runs the
+whole path on its own batch of 8 inside the timed region, and the record says what is in flight (`config`) and gives the strict
+one-batch-at-a-time figure beside the headline (`value_batch8_unpipelined`) and the figure with fresh input tensors every step
+(`value_fresh_inputs`).  `roofline` is the kernel family with the largest GPU-time share of the timed region (the DiT linears),
+measured in the timed configuration with HIP events on the launch stream - per launch as the contract defines it, plus
+`chip_level` (two launches share the chip) and `one_step_alone`; `roofline_lm` the LM's decode; every `traffic` comes from `rocprofv3 --pmc` over this very
+program (profiles/r04_bench_pmc.json; tests/micro/prof_r04.sh).  Secondary objects: `precise_mode`, `latency_b1`, `first_chunk`,
 `zero_shot_b4` (configs[2]), `hift_cfg5` (configs[4], output checked), `cpu_baseline`, `checked`.
 
 Prints ONE JSON line (rank 0).
@@ -199,7 +201,7 @@ def zero_shot_inputs(cfg, B=4, P=250):
     return inputs
 
 
-def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib, steps=3):
+def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib, steps=3, flow_workers=2):
     """BASELINE.json configs[2] as a secondary object: zero-shot with a 10 s prompt (30 prompt-text ids, 250 prompt speech
     tokens in the LM = a ~296-row prefill per sequence, 500 prompt mel frames: DiT sequence 650), batch 4, 75 forced tokens,
     steps one after the other on one stream."""
@@ -249,7 +251,7 @@ def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib, steps=3):
     torch.cuda.empty_cache()
     # the same workload through the software pipeline of the headline (one LM call per 4 steps = 16 sequences per weight pass)
     mp = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=B, max_text=64, max_prompt_tokens=P, max_tokens=N_TOK,
-                         rand_noise=noise, rand_ini=ri, sine_noise=sn, lm_group=4)
+                         rand_noise=noise, rand_ini=ri, sine_noise=sn, lm_group=4, flow_workers=flow_workers)
     mp.prepare_pipeline(0)
     k = 12
 
@@ -262,8 +264,8 @@ def bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib, steps=3):
     run_p()
     torch.cuda.synchronize()
     dtp = (time.perf_counter() - t2) / k
-    out["pipelined"] = {"ms_per_step": round(1e3 * dtp, 2), "audio_s_per_s": round(audio / dtp, 2), "steps": k, "lm_group": 4,
-                        "note": "tts_pipeline as in the headline run: the LM of 4 steps' batches in one call beside the flow decoder"}
+    out["pipelined"] = {"ms_per_step": round(1e3 * dtp, 2), "audio_s_per_s": round(audio / dtp, 2), "steps": k, "lm_group": 4, "flow_workers": flow_workers,
+                        "note": "tts_pipeline as in the headline run: the LM of 4 steps' batches in one call beside the flow decoders of flow_workers steps"}
     mp.close()
     del mp
     torch.cuda.empty_cache()
@@ -512,7 +514,7 @@ def main():
     # launched on) around every launch of one kernel family per pass - the DiT linears on the flow stream, then the LM's
     # decode products on the LM stream.  Not inside the timed pass itself: two event records per launch cost the recorded
     # stream a few per cent.  Event-to-event intervals of a kernel that shares the chip include the time its workgroups wait
-    # for CUs the other stream holds, exactly as rocprofv3's begin/end stamps do (profiles/r03_bench_kernel_stats.csv).
+    # for CUs the other stream holds, exactly as rocprofv3's begin/end stamps do (profiles/r04_bench_kernel_stats.csv).
     def events_pass(name):
         L.fy_prof_reset()
         L.fy_prof_only(name.encode())
@@ -677,7 +679,7 @@ def main():
         log("first streaming chunk")
         out["first_chunk"] = bench_first_chunk(cfg, sd_llm, sd_flow, sd_hift, dev, inputs)
         log("zero-shot batch 4 (config 3)")
-        out["zero_shot_b4"], zs_keep = bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib)
+        out["zero_shot_b4"], zs_keep = bench_zero_shot(cfg, sd_llm, sd_flow, sd_hift, dev, L, _lib, flow_workers=a.flow_workers)
         log("HiFT-only 32 x 10 000 frames (config 5)")
         model.close()
         del model, eng
