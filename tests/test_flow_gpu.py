@@ -151,6 +151,30 @@ def test_estimator_masked_rows(tiny):
     assert maxerr(y[:1], ref) < 4e-2
 
 
+def test_event_records_sum_and_union(tiny):
+    """The per-launch event records bench.py's roofline is built from: on ONE stream the launches of a name do not overlap, so the time
+    with at least one of them running (fy_prof_union, what `roofline.chip_level` divides by when two flow workers share the chip)
+    equals the sum of their own durations; both are positive and the launch count is the estimator's number of linears."""
+    from fangyan_tts_amd import _lib
+    eng, P, o = tiny
+    L = _lib.lib()
+    x, mu, cond, spks, t = dit_inputs(150)
+    d = lambda z: z.to(DEV)
+    args = (d(x), d(torch.ones(2, 1, x.shape[2])), d(mu), d(t), d(spks), d(cond))
+    eng.estimator(*args)
+    torch.cuda.synchronize()
+    L.fy_prof_reset(); L.fy_prof_only(b"gemm_bf16"); L.fy_prof_enable(1)
+    eng.estimator(*args)
+    torch.cuda.synchronize()
+    L.fy_prof_enable(0); L.fy_prof_only(None)
+    ms, work, n = _lib.prof_get("gemm_bf16")
+    union = _lib.prof_union("gemm_bf16")
+    L.fy_prof_reset()
+    assert 4 * eng.cfg.depth <= n <= 4 * eng.cfg.depth + 4 and ms > 0 and work > 0
+    assert union > 0 and abs(union - ms) <= 0.02 * ms + 1e-3, (union, ms)
+    assert _lib.prof_union("no such name") == 0.0
+
+
 def cfm_case(cfg, n, p):
     token = torch.from_numpy(synth.randint(f"in.flow.token.{n}", (1, n), 0, cfg.vocab))
     ptoken = torch.from_numpy(synth.randint(f"in.flow.ptoken.{p}", (1, p), 0, cfg.vocab))
