@@ -642,10 +642,21 @@ def main():
                 step()
             torch.cuda.synchronize()
             p_ms = 1e3 * (time.perf_counter() - t4) / 3
+            pp_ms = None
+            if pipelined:                                   # and the headline's own pipelined run in that mode
+                run(4)
+                torch.cuda.synchronize()
+                t5 = time.perf_counter()
+                run(a.steps)
+                torch.cuda.synchronize()
+                pp_ms = 1e3 * (time.perf_counter() - t5) / a.steps
         finally:
             model.flow_flags = 0
         precise = {"what": "one batch alone with the flow decoder in FY_PRECISE mode (meets rtol 1e-2 / atol 1e-4 against the fp32 estimator, tests/test_flow_gpu.py)",
                    "ms": round(p_ms, 2), "audio_s_per_s": round(audio_per_step / (p_ms * 1e-3), 2), "default_mode_ms": round(latency_ms, 2)}
+        if pp_ms:
+            precise["pipelined"] = {"ms_per_step": round(pp_ms, 2), "audio_s_per_s": round(audio_per_step / (pp_ms * 1e-3), 2), "steps": a.steps,
+                                    "note": "the timed run of the headline repeated with the flow decoder in FY_PRECISE"}
 
     out = {
         "metric": "synthesised audio sec/sec (RTF^-1) CosyVoice3-0.5B instruct, batch 8",
