@@ -29,6 +29,7 @@ struct GemmEpi {
     // lo = bf16(x - hi) - a_lo is the lo plane ([M][lda] like A); out_lo != null stores the result the same way (out = hi plane,
     // out_lo = lo plane, both bf16 [M][ldc]) for the next product, after the exact-tanh GELU (act) or the rotary embedding (rope)
     const bf16_t* a_lo = nullptr;
+    const bf16_t* a_lo2 = nullptr;     // the third plane of an EXACT three-way split x = hi + mid (a_lo) + lo (a_lo2): gemm_exact3
     void* out_lo = nullptr;
 #ifdef FY_GEMM_STAMPS
     int stamp_slot = 0;                // tests/micro/gemm_stamps.hip: which 4096-workgroup slot of the stamp buffer this launch writes
@@ -52,6 +53,13 @@ int gemm_split(const bf16_t* A_hi, int lda, const bf16_t* W, int M, int N, int K
 // A: fp32 [M][lda], split EXACTLY into bf16 hi + mid + lo (3 MFMAs per fragment): with bf16-exact W every product is exact and
 // the accumulation is fp32 - the LM prefill over many rows (same fidelity as gemv_bf16w, whose 8-row form re-streams the weights)
 int gemm_f32a_exact(const float* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st);
+
+// The same product with A already split: A_hi + epi.a_lo + epi.a_lo2, three bf16 planes [M][lda] (split3_planes), on the LDS-DMA
+// ring kernel - three A tiles per stage, three MFMAs per fragment pair into one accumulator (N % 128 == 0, K % 32 == 0).
+int gemm_exact3(const bf16_t* A_hi, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st);
+bool gemm_exact3_supported(int N, int K);
+// fp32 [rows][ld_src] (cols used) -> three bf16 planes [rows][cols]: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)
+int split3_planes(const float* src, int ld_src, int rows, int cols, bf16_t* hi, bf16_t* mid, bf16_t* lo, hipStream_t st);
 
 // fp32 [n] -> bf16 [n]
 int cast_f32_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t st);

@@ -282,8 +282,8 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     constexpr int NWAVE = BM == 128 ? 4 : 8;                             // BM 128 (with BN 128): 2 x 2 waves of 64x64, 48 KB ring, three workgroups per CU
     constexpr int WN = BN / 64, WM = NWAVE / WN, MI = BM / WM / 32;       // waves along N / M, 32-row tiles per wave
-    static_assert(!SP || (MF && !STAG), "the split-operand form exists for the 16x16x32 products without staggered wave groups");
-    constexpr int APL = SP ? 2 : 1;                                       // A planes per stage
+    static_assert(!SP || (MF && !STAG), "the split-operand forms exist for the 16x16x32 products without staggered wave groups");
+    constexpr int APL = SP + 1;                                           // A planes per stage: 1, 2 (hi + lo: gemm_split) or 3 (hi + mid + lo: gemm_exact3)
     // DE: the direct epilogue of the 16x16x32 form (at the end of the kernel).  The products are taken TRANSPOSED - the W fragment
     // as the instruction's first operand - so a lane ends up with one output row's values, and W rows are dealt to the four
     // column tiles j as local column (c >> 2) * 16 + 4 j + (c & 3) for instruction index c, so those values are 16 CONSECUTIVE
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     for (int i = 0; i < NA; ++i) {
         const int j = i * NWAVE + wid;
         const int row = (SP ? j % (BM / 16) : j) * 16 + (lane >> 2), c = (lane & 3) ^ SW(row);
-        const bf16_t* Ap = (SP && j >= BM / 16) ? e.a_lo : A;          // wave-uniform
+        const int pl = SP ? j / (BM / 16) : 0;                         // wave-uniform: the plane this wave-instruction fills
+        const bf16_t* Ap = pl == 0 ? A : (pl == 1 ? e.a_lo : e.a_lo2);
         a_src[i] = Ap + (long)min(m0 + row, M - 1) * lda + c * 8;
     }
 #pragma unroll
@@ -493,22 +494,24 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
             // The refill of the slot freed by the barrier goes out one DMA at a time BETWEEN the MFMA groups, after this stage's
             // fragment reads: a DMA's issue waits for the CU's one address path (1 KB at <= 64 B per clock, shared by every wave of
             // the CU), and issued as a burst after the barrier - every wave of the workgroup in step - nothing computes meanwhile.
-            frag_ab fl[SP ? 2 : 1][SP ? MI : 1];
+            frag_ab fl[SP ? SP : 1][SP ? 2 : 1][SP ? MI : 1];
 #pragma unroll
             for (int j = 0; j < 4; ++j) fb[j >> 1][j & 1] = *reinterpret_cast<const frag_ab*>(sb + b16[j]);
 #pragma unroll
             for (int i = 0; i < 2 * MI; ++i) fa[i & 1][i >> 1] = *reinterpret_cast<const frag_ab*>(sb + a16[i]);
             if constexpr (SP) {
 #pragma unroll
-                for (int i = 0; i < 2 * MI; ++i) fl[i & 1][i >> 1] = *reinterpret_cast<const frag_ab*>(sb + a16[i] + BM * G2_BK * 2);
+                for (int p = 0; p < SP; ++p)
+#pragma unroll
+                    for (int i = 0; i < 2 * MI; ++i) fl[p][i & 1][i >> 1] = *reinterpret_cast<const frag_ab*>(sb + a16[i] + (p + 1) * BM * G2_BK * 2);
             }
-            constexpr int GR = (SP ? 2 : 1) * 2 * MI, ND = NA + NB;      // MFMA groups (four products each) and DMAs per stage
+            constexpr int GR = APL * 2 * MI, ND = NA + NB;               // MFMA groups (four products each) and DMAs per stage
 #pragma unroll
             for (int g = 0; g < GR; ++g) {
                 const int i = g % (2 * MI);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const frag_ab fx = g < 2 * MI ? fa[i & 1][i >> 1] : fl[i & 1][i >> 1];
+                    const frag_ab fx = g < 2 * MI ? fa[i & 1][i >> 1] : fl[SP ? g / (2 * MI) - 1 : 0][i & 1][i >> 1];
                     acc4[i][j] = DE ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j >> 1][j & 1], fx, acc4[i][j], 0, 0, 0)
                                     : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fb[j >> 1][j & 1], acc4[i][j], 0, 0, 0);
                 }
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
 template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0, int SP = 0>
 static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static bool attr_set = false;
-    const size_t lds = (size_t)3 * ((SP ? 2 : 1) * BM + BN) * G2_BK * 2;          // 256x256: 96 KB; 320x256: 108 KB (one workgroup per CU); 256x128: 72 KB (two); 128x128: 48 KB (three); split operand: 256x128 120 KB (one), 128x128 72 KB (two)
+    const size_t lds = (size_t)3 * ((SP + 1) * BM + BN) * G2_BK * 2;          // 256x256: 96 KB; 320x256: 108 KB (one workgroup per CU); 256x128: 72 KB (two); 128x128: 48 KB (three); split operand: 256x128 120 KB (one), 128x128 72 KB (two)
     if (!attr_set) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN, BM, STAG, MF, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
@@ -885,6 +888,51 @@ int gemm_split(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, c
     }
     FY_CHECK(!epi.out_bf16 && epi.act == ACT_NONE && !epi.rope, FY_ERR_ARG, "gemm_split: outputs are fp32, the gated residual, or split bf16 planes");
     return gemm_split_launch<2>(A, lda, W, M, N, K, epi, st);
+}
+
+bool gemm_exact3_supported(int N, int K) { return N % 128 == 0 && K % G2_BK == 0; }
+
+int gemm_exact3(const bf16_t* A_hi, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
+    FY_TRY(gemm_check(A_hi, lda, W, M, N, K, epi, 2));
+    FY_CHECK(gemm_exact3_supported(N, K), FY_ERR_ARG, "gemm_exact3: N %d must be a multiple of 128 and K %d of 32", N, K);
+    FY_CHECK(epi.a_lo && epi.a_lo2 && (((uintptr_t)epi.a_lo | (uintptr_t)epi.a_lo2) & 15) == 0, FY_ERR_ARG, "gemm_exact3: a plane of A is missing or misaligned");
+    FY_CHECK((epi.mode == EPI_GATE_RESID || !epi.out_bf16) && !epi.out_lo && epi.act == ACT_NONE && !epi.rope, FY_ERR_ARG, "gemm_exact3: outputs are fp32 or the gated residual");
+    FY_CHECK((((uintptr_t)epi.out | (uintptr_t)epi.resid) & 15) == 0 && epi.ldc % 4 == 0, FY_ERR_ARG, "gemm_exact3: misaligned output");
+    ProfScope prof("gemm_exact", 2.0 * M * N * K, st);
+    // 128x128 tiles, 96 KB of ring (one workgroup per CU): the LM prefill's products have 49-532 tiles
+    if (epi.mode == EPI_GATE_RESID) return gemm_launch_256<3, 128, 128, 0, 1, 2>(A_hi, lda, W, M, N, K, epi, st);
+    return gemm_launch_256<2, 128, 128, 0, 1, 2>(A_hi, lda, W, M, N, K, epi, st);
+}
+
+__global__ void split3_planes_k(const float* __restrict__ src, int ld_src, int rows, int cols, bf16_t* __restrict__ hi, bf16_t* __restrict__ mid, bf16_t* __restrict__ lo) {
+    const long n4 = (long)rows * (cols / 4);
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long r = i / (cols / 4);
+        const int c = (int)(i % (cols / 4)) * 4;
+        const float4 x = *reinterpret_cast<const float4*>(src + r * ld_src + c);
+        const float f[4] = {x.x, x.y, x.z, x.w};
+        uint32_t h[4], m[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                   // split8_3's arithmetic
+            const __bf16 hb = (__bf16)f[j];
+            const float r1 = f[j] - (float)hb;
+            const __bf16 mb = (__bf16)r1;
+            const float r2 = r1 - (float)mb;
+            const __bf16 lb = (__bf16)r2;
+            h[j] = __builtin_bit_cast(unsigned short, hb); m[j] = __builtin_bit_cast(unsigned short, mb); l[j] = __builtin_bit_cast(unsigned short, lb);
+        }
+        const long o = r * cols + c;
+        *reinterpret_cast<uint2*>(hi + o) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+        *reinterpret_cast<uint2*>(mid + o) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
+        *reinterpret_cast<uint2*>(lo + o) = make_uint2(l[0] | (l[1] << 16), l[2] | (l[3] << 16));
+    }
+}
+int split3_planes(const float* src, int ld_src, int rows, int cols, bf16_t* hi, bf16_t* mid, bf16_t* lo, hipStream_t st) {
+    FY_CHECK(src && hi && mid && lo && rows >= 1 && cols >= 4 && cols % 4 == 0 && ld_src % 4 == 0, FY_ERR_ARG, "split3_planes: bad arguments");
+    const long n4 = (long)rows * (cols / 4);
+    hipLaunchKernelGGL(split3_planes_k, dim3((unsigned)std::min<long>(4096, (n4 + 255) / 256)), dim3(256), 0, st, src, ld_src, rows, cols, hi, mid, lo);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
 }
 
 int gemm_f32a_exact(const float* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {

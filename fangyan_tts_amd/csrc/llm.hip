@@ -47,6 +47,8 @@ struct fy_llm {
     int B = 0;
     int step_next = 0, steps_cap = 0;      // fy_llm_begin / fy_llm_step: next decode step of the generation in progress, and its bound
     bool all_done = false;                 // every sequence of that generation has ended: further steps are no-ops
+    bf16_t* pl3 = nullptr;                                    // prefill GEMM path on the ring kernel: the A operand as three bf16 planes [3][rows][<= inter]
+    bool prefill_ring = true;                                 // FY_LLM_PREFILL_RING=0: the register-staged exact-split kernel (A/B; ids identical)
     float *gu = nullptr, *actf = nullptr, *ones = nullptr;   // prefill GEMM path: gate/up products [rows][2 inter], SwiGLU [rows][inter], a vector of ones (the gate of h += W x)
     DecodePlan* dec = nullptr;             // persistent one-launch decode step (llm_decode.hip) when the architecture fits
     int prefill_gemm_rows = 320;           // FY_LLM_PREFILL_GEMM_ROWS: from this many prefill rows on, the tiled GEMMs
@@ -81,13 +83,25 @@ __global__ void embed_rows_k(const int* __restrict__ src, const bf16_t* __restri
 }
 
 // Qwen2RMSNorm: w * (x * rsqrt(mean(x^2) + eps)).  One wave per row.
-__global__ __launch_bounds__(256) void rmsnorm_k(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int R, int H, float eps) {
+// planes != null: the result leaves as the three bf16 planes of its exact split ([3][R][H]: the operand of gemm_exact3) instead of fp32
+__global__ __launch_bounds__(256) void rmsnorm_k(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int R, int H, float eps,
+                                                 bf16_t* __restrict__ planes = nullptr) {
     int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= R) return;
     const float* p = x + (long)row * H;
     float s = 0.f;
     for (int c = lane; c < H; c += 64) s += p[c] * p[c];
     float r = rsqrtf(wave_sum(s) / H + eps);
+    if (planes) {
+        const long RH = (long)R * H;
+        for (int c = lane; c < H; c += 64) {
+            unsigned h, m, l;
+            gv32_split3(w[c] * (p[c] * r), h, m, l);
+            const long o = (long)row * H + c;
+            planes[o] = (bf16_t)h; planes[RH + o] = (bf16_t)m; planes[2 * RH + o] = (bf16_t)l;
+        }
+        return;
+    }
     for (int c = lane; c < H; c += 64) y[(long)row * H + c] = w[c] * (p[c] * r);
 }
 
@@ -416,7 +430,22 @@ __global__ __launch_bounds__(256) void sample_ras_k(const float* __restrict__ lo
 }
 
 // act[r][i] = silu(gu[r][2i]) * gu[r][2i+1]: the gate / up rows are interleaved (Qwen2MLP: down(silu(gate(x)) * up(x)))
-__global__ void swiglu_rows_k(const float* __restrict__ gu, float* __restrict__ act, long n, int inter) {
+// planes != null: as three bf16 planes [3][n] instead of fp32 (two columns per thread)
+__global__ void swiglu_rows_k(const float* __restrict__ gu, float* __restrict__ act, long n, int inter, bf16_t* __restrict__ planes = nullptr) {
+    if (planes) {
+        for (long i = (blockIdx.x * 256L + threadIdx.x) * 2; i < n; i += (long)gridDim.x * 512) {      // inter is even: a pair stays in its row
+            const long r = i / inter;
+            const int c = (int)(i % inter);
+            const float4 p = *reinterpret_cast<const float4*>(gu + r * 2 * inter + 2 * c);
+            unsigned h0, m0, l0, h1, m1, l1;
+            gv32_split3(act_silu(p.x) * p.y, h0, m0, l0);
+            gv32_split3(act_silu(p.z) * p.w, h1, m1, l1);
+            *reinterpret_cast<unsigned*>(planes + i) = h0 | (h1 << 16);
+            *reinterpret_cast<unsigned*>(planes + n + i) = m0 | (m1 << 16);
+            *reinterpret_cast<unsigned*>(planes + 2 * n + i) = l0 | (l1 << 16);
+        }
+        return;
+    }
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const long r = i / inter;
         const int c = (int)(i % inter);
@@ -593,6 +622,8 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
     if (hipMemsetAsync(l->counters, 0, (gemv_counter_ints((int)R, H, I) + 16) * sizeof(int), st) != hipSuccess) { fy_set_error("fy_llm_create: memset failed"); return fail(FY_ERR_HIP); }
     TRYC(l->pool.alloc(&l->logp_keep, (size_t)FY_LLM_KEEP_LOGP * B * NS));
     TRYC(l->pool.alloc(&l->gu, R * 2 * (size_t)I)); TRYC(l->pool.alloc(&l->actf, R * (size_t)I)); TRYC(l->pool.alloc(&l->ones, (size_t)H));
+    TRYC(l->pool.alloc(&l->pl3, 3 * R * (size_t)std::max(H, I)));
+    l->prefill_ring = !(getenv("FY_LLM_PREFILL_RING") && atoi(getenv("FY_LLM_PREFILL_RING")) == 0);
     hipLaunchKernelGGL(fill_k, dim3(cdiv(H, 256)), dim3(256), 0, st, l->ones, 1.0f, H);
     TRYC(l->pool.alloc(&l->row_seq, R)); TRYC(l->pool.alloc(&l->row_pos, R)); TRYC(l->pool.alloc(&l->row_src, R));
     TRYC(l->pool.alloc(&l->last_row, B)); TRYC(l->pool.alloc(&l->st, 8 * B)); TRYC(l->pool.alloc(&l->seq_ids, B));
@@ -637,23 +668,34 @@ static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, 
         float* Kc = l->Kc + (size_t)i * l->cache_layer();
         float* Vc = l->Vc + (size_t)i * l->cache_layer();
         if (gemm_path) {
-            hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln1, l->xn, R, H, c.rms_eps);
+            // Round 4: the exact three-way split products on the LDS-DMA ring kernel (gemm_exact3) - the operand is split into its
+            // planes once by a small kernel instead of by every column tile's workgroup, and the K loop is the DiT linears'.
+            const bool ring = l->prefill_ring && gemm_exact3_supported(QKV, H) && gemm_exact3_supported(H, H) && gemm_exact3_supported(2 * I, H) && gemm_exact3_supported(H, I);
+            // exact(A, K, W, N, e): A == nullptr means the producer already left the planes in pl3
+            auto exact = [&](const float* A, int K, const bf16_t* W, int N, GemmEpi& e) -> int {
+                if (!ring) return gemm_f32a_exact(A, K, W, R, N, K, e, st);
+                bf16_t *p0 = l->pl3, *p1 = p0 + (size_t)R * K, *p2 = p1 + (size_t)R * K;
+                if (A) FY_TRY(split3_planes(A, K, R, K, p0, p1, p2, st));
+                e.a_lo = p1; e.a_lo2 = p2;
+                return gemm_exact3(p0, K, W, R, N, K, e, st);
+            };
+            hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln1, l->xn, R, H, c.rms_eps, ring ? l->pl3 : nullptr);
             GemmEpi q;
             q.bias = k.bqkv; q.out = l->qkv; q.out_bf16 = 0; q.ldc = QKV;
-            FY_TRY(gemm_f32a_exact(l->xn, H, k.rqkv, R, QKV, H, q, st));
+            FY_TRY(exact(ring ? nullptr : l->xn, H, k.rqkv, QKV, q));
             hipLaunchKernelGGL(rope_kv_k, dim3(R), dim3(256), 0, st, l->qkv, Kc, Vc, row_seq, row_pos, l->inv_freq, c.q_heads, c.kv_heads, l->max_ctx);
             FY_TRY(llm_attention(l->qkv, QKV, Kc, Vc, row_seq, row_pos, l->ao, H, R, c.q_heads, c.kv_heads, l->max_ctx, st));
             GemmEpi o;
             o.mode = EPI_GATE_RESID; o.resid = l->h; o.gate = l->ones; o.ldc = H;
-            FY_TRY(gemm_f32a_exact(l->ao, H, k.ro, R, H, H, o, st));
-            hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln2, l->xn, R, H, c.rms_eps);
+            FY_TRY(exact(l->ao, H, k.ro, H, o));
+            hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln2, l->xn, R, H, c.rms_eps, ring ? l->pl3 : nullptr);
             GemmEpi g;
             g.out = l->gu; g.out_bf16 = 0; g.ldc = 2 * I;
-            FY_TRY(gemm_f32a_exact(l->xn, H, k.rgu, R, 2 * I, H, g, st));
-            hipLaunchKernelGGL(swiglu_rows_k, dim3(std::min(4096, cdiv(R * I, 256))), dim3(256), 0, st, l->gu, l->actf, (long)R * I, I);
+            FY_TRY(exact(ring ? nullptr : l->xn, H, k.rgu, 2 * I, g));
+            hipLaunchKernelGGL(swiglu_rows_k, dim3(std::min(4096, cdiv(R * I, ring ? 512 : 256))), dim3(256), 0, st, l->gu, l->actf, (long)R * I, I, ring ? l->pl3 : nullptr);
             GemmEpi d;
             d.mode = EPI_GATE_RESID; d.resid = l->h; d.gate = l->ones; d.ldc = H;
-            FY_TRY(gemm_f32a_exact(l->actf, I, k.rd, R, H, I, d, st));
+            FY_TRY(exact(ring ? nullptr : l->actf, I, k.rd, H, d));
             continue;
         }
         if (l->gv32) {
