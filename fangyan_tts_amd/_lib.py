@@ -131,6 +131,7 @@ def _declare(L):
     L.fy_llm_decode_mode.argtypes = [vp]
     L.fy_debug_decode_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
     L.fy_debug_decode32_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
+    L.fy_debug_gemm_exact.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp, vp]
 
 
 def tensor_table(weights):

@@ -935,6 +935,21 @@ int split3_planes(const float* src, int ld_src, int rows, int cols, bf16_t* hi, 
     return FY_OK;
 }
 
+// test hook (tests/test_llm_gpu.py): out [M][N] fp32 = A [M][K] fp32 x W [N][K] bf16 (+ bias) through the exact three-way split, on the
+// ring kernel (ring != 0; planes = scratch of 3 M K bf16) or on the register-staged kernel
+extern "C" int fy_debug_gemm_exact(const float* A, const void* W, int32_t M, int32_t N, int32_t K, const float* bias, float* out, int32_t ring,
+                                   void* planes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    GemmEpi e;
+    e.bias = bias; e.out = out; e.out_bf16 = 0; e.ldc = N;
+    if (!ring) return gemm_f32a_exact(A, K, (const bf16_t*)W, M, N, K, e, st);
+    FY_CHECK(planes, FY_ERR_ARG, "fy_debug_gemm_exact: the ring form needs the planes scratch");
+    bf16_t *p0 = (bf16_t*)planes, *p1 = p0 + (size_t)M * K, *p2 = p1 + (size_t)M * K;
+    FY_TRY(split3_planes(A, K, M, K, p0, p1, p2, st));
+    e.a_lo = p1; e.a_lo2 = p2;
+    return gemm_exact3(p0, K, (const bf16_t*)W, M, N, K, e, st);
+}
+
 int gemm_f32a_exact(const float* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     FY_TRY(gemm_check(A, lda, W, M, N, K, epi, 4));
     ProfScope prof("gemm_exact", 2.0 * M * N * K, st);

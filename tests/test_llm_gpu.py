@@ -370,3 +370,29 @@ def test_ras_full_size(full):
             assert out[0, : int(out_n[0])].cpu().tolist() == ref
     finally:
         full.set_sampler("greedy")
+
+
+@pytest.mark.parametrize("M,N,K", [(800, 1152, 896), (296, 896, 4864), (37, 256, 256)])
+def test_exact_split_products_ring_and_register_staged(M, N, K):
+    """The LM prefill's GEMMs (round 4: three bf16 planes per stage on the LDS-DMA ring kernel, `gemm_exact3`; round 2's register-staged
+    kernel is the fallback): with bf16 weights every product of the exact split x = hi + mid + lo is exact and the sums are fp32, so
+    both forms sit within fp32 accumulation error of the float64 product - rows that do not fill a tile, K = 4864 and a wide
+    dynamic range in A included - and agree with each other to the same bound."""
+    from fangyan_tts_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = (torch.randn(M, K, generator=g) * torch.exp(3.0 * torch.randn(M, 1, generator=g))).to(DEV)
+    W = torch.randn(N, K, generator=g).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = A.double() @ W.double().t() + bias.double()
+    bound = (A.abs().double() @ W.abs().double().t()) * (K * 2.0 ** -24) + 1e-30          # fp32 accumulation of K exact products
+    outs = []
+    for ring in (1, 0):
+        out = torch.full((M, N), float("nan"), device=DEV)
+        planes = torch.empty(3 * M * K, dtype=torch.bfloat16, device=DEV)
+        _lib.check(L.fy_debug_gemm_exact(A.data_ptr(), W.data_ptr(), M, N, K, bias.data_ptr(), out.data_ptr(), ring, planes.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        assert bool(((out.double() - ref).abs() <= bound).all()), (ring, float(((out.double() - ref).abs() / bound).max()))
+        outs.append(out)
+    assert bool(((outs[0].double() - outs[1].double()).abs() <= 2 * bound).all())
