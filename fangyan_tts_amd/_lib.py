@@ -132,6 +132,7 @@ def _declare(L):
     L.fy_debug_decode_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
     L.fy_debug_decode32_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
     L.fy_debug_gemm_exact.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp, vp]
+    L.fy_debug_gemm_bf16.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, i32, vp, i32, vp]
 
 
 def tensor_table(weights):

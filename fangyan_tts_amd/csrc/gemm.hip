@@ -935,6 +935,20 @@ int split3_planes(const float* src, int ld_src, int rows, int cols, bf16_t* hi, 
     return FY_OK;
 }
 
+// test hook (tests/test_flow_gpu.py): out [M][N] bf16 = act(A [M][K] bf16 x W [N][K] bf16 + bias) with one tiling forced for every shape
+// (gemm_launch2's override codes; 0 = the automatic choice) - every tiling and both epilogues must give the same bits
+extern "C" int fy_debug_gemm_bf16(const void* A, const void* W, int32_t M, int32_t N, int32_t K, const float* bias, void* out, int32_t gelu,
+                                  int32_t tile, const float* rope, int32_t rope_T, void* stream) {
+    GemmEpi e;
+    e.bias = bias; e.out = out; e.out_bf16 = 1; e.ldc = N; e.act = gelu ? ACT_GELU_TANH : ACT_NONE;
+    if (rope) { e.rope = reinterpret_cast<const float2*>(rope); e.rope_T = rope_T; e.rope_half = 32; e.rope_stride = N / 3; }   // the DiT's qkv: head 0 of q and of k
+    const int was = gemm_tile_override;
+    gemm_tile_override = tile;
+    const int rc = gemm_bf16((const bf16_t*)A, K, (const bf16_t*)W, M, N, K, e, (hipStream_t)stream);
+    gemm_tile_override = was;
+    return rc;
+}
+
 // test hook (tests/test_llm_gpu.py): out [M][N] fp32 = A [M][K] fp32 x W [N][K] bf16 (+ bias) through the exact three-way split, on the
 // ring kernel (ring != 0; planes = scratch of 3 M K bf16) or on the register-staged kernel
 extern "C" int fy_debug_gemm_exact(const float* A, const void* W, int32_t M, int32_t N, int32_t K, const float* bias, float* out, int32_t ring,

@@ -151,6 +151,45 @@ def test_estimator_masked_rows(tiny):
     assert maxerr(y[:1], ref) < 4e-2
 
 
+@pytest.mark.parametrize("M,N,K,gelu,rope_T", [(1300, 1024, 1024, 0, 0), (800, 2048, 1024, 1, 0), (650, 3072, 1024, 0, 0), (400, 1024, 2048, 0, 0),
+                                               (1300, 3072, 1024, 0, 650)])
+def test_ring_gemm_tilings_and_epilogues_give_the_same_bits(M, N, K, gelu, rope_T):
+    """Every tiling of the DiT linears' ring kernel accumulates K in the same order, and the direct register-to-memory epilogue of
+    the 16x16x32 forms (transposed products, W rows dealt so that a lane holds 16 consecutive columns; round 4) stores the very values the
+    LDS epilogue of the 32x32x16 forms stores: outputs are BIT-identical across the automatic choice, 256x256 / 320x256 tiles on
+    32x32x16 (LDS epilogue), 256x128 / 128x128 / 320x256 / 256x256 on 16x16x32 (direct epilogue) - ragged last row tiles included -
+    and within bf16 rounding of the float64 product."""
+    from fangyan_tts_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(N + K + M)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    rope = None
+    if rope_T:            # the qkv product's rotary epilogue (position = row % rope_T, 32 (cos, sin) pairs per position, q's and k's head 0)
+        ang = torch.arange(rope_T, dtype=torch.float64)[:, None] * torch.exp(-torch.arange(32, dtype=torch.float64) / 4.0)[None, :]
+        rope = torch.stack([ang.cos(), ang.sin()], dim=-1).float().contiguous().to(DEV)
+    outs = {}
+    for tile in (0, 256, 1320, 2002, 2003, 3320, 3256, 2256):
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        _lib.check(L.fy_debug_gemm_bf16(A.data_ptr(), W.data_ptr(), M, N, K, bias.data_ptr(), out.data_ptr(), gelu, tile,
+                                        rope.data_ptr() if rope is not None else None, rope_T, None))
+        torch.cuda.synchronize()
+        outs[tile] = out
+    for tile, out in outs.items():
+        assert torch.equal(out.view(torch.int16), outs[0].view(torch.int16)), tile
+    ref = A.double() @ W.double().t() + bias.double()
+    if gelu:
+        ref = torch.nn.functional.gelu(ref, approximate="tanh")
+    if rope_T:            # x-transformers' interleaved pairs on the first 64 columns of q and of k
+        cs = rope.double().cpu()[torch.arange(M) % rope_T].to(ref.device)
+        for base in (0, N // 3):
+            a, b = ref[:, base:base + 64:2].clone(), ref[:, base + 1:base + 64:2].clone()
+            ref[:, base:base + 64:2] = a * cs[:, :, 0] - b * cs[:, :, 1]
+            ref[:, base + 1:base + 64:2] = b * cs[:, :, 0] + a * cs[:, :, 1]
+    assert maxerr(outs[0].float(), ref.float()) < 3e-2
+
+
 def test_event_records_sum_and_union(tiny):
     """The per-launch event records bench.py's roofline is built from: on ONE stream the launches of a name do not overlap, so the time
     with at least one of them running (fy_prof_union, what `roofline.chip_level` divides by when two flow workers share the chip)
