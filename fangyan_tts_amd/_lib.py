@@ -36,7 +36,7 @@ class FlowConfig(C.Structure):
 class LlmConfig(C.Structure):
     _fields_ = [("hidden", C.c_int32), ("layers", C.c_int32), ("q_heads", C.c_int32), ("kv_heads", C.c_int32),
                 ("head_dim", C.c_int32), ("inter", C.c_int32), ("vocab", C.c_int32), ("speech_tokens", C.c_int32),
-                ("rms_eps", C.c_float), ("rope_theta", C.c_float)]
+                ("rms_eps", C.c_float), ("rope_theta", C.c_float), ("weight_planes", C.c_int32)]
 
 
 FY_PRECISE = 1
@@ -129,6 +129,7 @@ def _declare(L):
     L.fy_stream_destroy.argtypes = [vp]
     L.fy_llm_set_decode_mode.argtypes = [vp, i32]
     L.fy_llm_decode_mode.argtypes = [vp]
+    L.fy_llm_weight_planes.argtypes = [vp]
     L.fy_debug_decode_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
     L.fy_debug_decode32_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
     L.fy_debug_gemm_exact.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp, vp]

@@ -410,15 +410,16 @@ class CosyVoice3Model:
         threads = [th.Thread(target=producer, args=(i,), daemon=True) for i in range(n_prod)]
         threads += [th.Thread(target=feeder, daemon=True)] + [th.Thread(target=worker, args=(w,), daemon=True) for w in range(n_flow)]
         with self._take_all_lanes():
-            was_persistent = [e.persistent for e in self.llms]
+            was_persistent = [e.decode_mode for e in self.llms]
             # An LM call of 9 .. 32 sequences (lm_group batches) decodes with the few-CU persistent step (csrc/llm_decode32.hip: one launch
             # of 76 resident workgroups per token step): beside the flow stream a call takes 132 ms where the per-operation launches
-            # took 266 (FY_PIPE_TRACE) - the LM is no longer what the pipeline waits for.  Up to 8 sequences per call keep the
-            # per-operation launches: the 8-row persistent step holds 152 CUs while it runs.  FY_PIPE_LM_PERSISTENT32=0: always per-operation.
+            # took 266 (FY_PIPE_TRACE) - the LM is no longer what the pipeline waits for.  Decode mode 2 = ONLY that step: a call of up
+            # to 8 sequences (a tail group, a warm-up) runs it too and never the 8-row persistent step, whose 152 workgroups would wait
+            # for residency beside the flow streams.  FY_PIPE_LM_PERSISTENT32=0: always per-operation.
             import os as _os
-            p32 = bool(int(_os.environ.get("FY_PIPE_LM_PERSISTENT32", "1"))) and self.lm_group * self.max_batch > 8
+            p32 = bool(int(_os.environ.get("FY_PIPE_LM_PERSISTENT32", "1")))
             for e in self.llms:
-                e.set_decode_mode(p32)
+                e.set_decode_mode(2 if p32 else 0)
             box["base"] = self._next_batch_ids(len(batches))
             for t in threads:
                 t.start()

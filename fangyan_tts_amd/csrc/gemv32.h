@@ -22,6 +22,10 @@ size_t gv32_counter_ints(int R, int N, int K);
 enum { GV32_STORE = 0, GV32_ADD_IMG = 1, GV32_SWIGLU_IMG = 2 };
 struct Gv32Args {
     const bf16_t* W = nullptr;       // gemv_pack's fragment order [N/32][K/16][64][8]
+    // exact-weights mode (general fp32 checkpoints): the matrix is W + W_lo, W = bf16(w), W_lo = bf16(w - W), same order; per
+    // fragment the hi plane meets all three operand planes and the lo plane the two leading ones (the dropped lo x lo term is
+    // 2^-26 of the product) - five MFMAs instead of three.  null: one plane (weights that are bf16-representable)
+    const bf16_t* W_lo = nullptr;
     const bf16_t* img = nullptr;     // A image of the R x K operand
     int R = 0, N = 0, K = 0;
     // fused RMSNorm of the operand (the image holds norm_w * x): acc *= rsqrt(sum of the n_ssq partials of the row / K + eps)

@@ -30,7 +30,7 @@ __device__ __forceinline__ gv_frag gv32_ld(const bf16_t* p) {
     return __builtin_bit_cast(gv_frag, r);
 }
 
-template <int NT, int NW, int DB>
+template <int NT, int NW, int DB, bool XW = false>
 __global__ __launch_bounds__(NW * 64) void gemv32_k(const Gv32Args a) {
     extern __shared__ __attribute__((aligned(16))) float red[];          // [NW][NT][16][64]: the waves' accumulators (dynamic: 64 KB at NT = 4)
     __shared__ float rstd_s[32];
@@ -55,19 +55,24 @@ __global__ __launch_bounds__(NW * 64) void gemv32_k(const Gv32Args a) {
     const bf16_t* wt[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) wt[t] = a.W + (long)min(tile0 + t, NT32 - 1) * K16 * 512 + lane * 8;
+    const long w_lo = XW ? a.W_lo - a.W : 0;                 // the lo plane's fragments sit at the same offsets
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     for (int kb = kbeg + wid; kb < kend; kb += NW * DB) {
-        gv_frag b[NT][DB], af[DB][3];
+        gv_frag b[NT][DB], b2[XW ? NT : 1][DB], af[DB][3];
 #pragma unroll
         for (int u = 0; u < DB; ++u) {
             const int kk = kb + u * NW;
             if (kk < kend) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) b[t][u] = gv32_ld_nt(wt[t] + (long)kk * 512);
+                if constexpr (XW) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) b2[t][u] = gv32_ld_nt(wt[t] + w_lo + (long)kk * 512);
+                }
 #pragma unroll
                 for (int p = 0; p < 3; ++p) af[u][p] = gv32_ld(ap + ((long)kk * 3 + p) * 512);
             }
@@ -80,6 +85,12 @@ __global__ __launch_bounds__(NW * 64) void gemv32_k(const Gv32Args a) {
                 for (int p = 0; p < 3; ++p)
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u][p], b[t][u], acc[t], 0, 0, 0);
+                if constexpr (XW) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[u][p], b2[t][u], acc[t], 0, 0, 0);
+                }
             }
         }
     }
@@ -232,7 +243,7 @@ static int gv32_env(const char* name, int dflt) {
 
 int gemv32(const Gv32Args& a, hipStream_t st) {
     FY_CHECK(a.W && a.img && a.R >= 1 && a.N >= 1 && a.K >= 16 && a.K % 16 == 0, FY_ERR_ARG, "gemv32: bad arguments R %d N %d K %d", a.R, a.N, a.K);
-    FY_CHECK((((uintptr_t)a.W | (uintptr_t)a.img) & 15) == 0, FY_ERR_ARG, "gemv32: weights and image must be 16-B aligned");
+    FY_CHECK((((uintptr_t)a.W | (uintptr_t)a.W_lo | (uintptr_t)a.img) & 15) == 0, FY_ERR_ARG, "gemv32: weights and image must be 16-B aligned");
     FY_CHECK(!a.ssq || (a.n_ssq >= 1 && a.n_ssq <= 32), FY_ERR_ARG, "gemv32: %d partial sums of squares per row (1..32)", a.n_ssq);
     if (a.mode == GV32_STORE) FY_CHECK(a.y && a.ldy >= a.N, FY_ERR_ARG, "gemv32: GV32_STORE needs y");
     if (a.mode == GV32_ADD_IMG)
@@ -240,7 +251,7 @@ int gemv32(const Gv32Args& a, hipStream_t st) {
                  "gemv32: GV32_ADD_IMG needs y (16-B aligned rows), N %% 32 == 0, and ln_next + ssq_out with img_out");
     if (a.mode == GV32_SWIGLU_IMG) FY_CHECK(a.img_out && a.N % 32 == 0, FY_ERR_ARG, "gemv32: GV32_SWIGLU_IMG needs img_out and N %% 32 == 0");
     const int tiles = cdiv(a.N, 32), Z = cdiv(a.R, 32);
-    ProfScope prof("gemv", 2.0 * a.N * a.K, st);                 // work = the product's bf16 weight bytes
+    ProfScope prof("gemv", (a.W_lo ? 4.0 : 2.0) * a.N * a.K, st);                 // work = the product's bf16 weight bytes
     // Launch shapes (tests/micro/gemv32_bench.hip): K slices only for the long K of the down projection; two tiles per block
     // where one tile per block would need a second round of blocks (gate/up: 304 tiles); 8 waves where few tiles exist
     static const int ks_down = gv32_env("FY_GV32_KS", 8), nt2_from = gv32_env("FY_GV32_NT2_FROM", 257), nw8_below = gv32_env("FY_GV32_NW8_BELOW", 128);
@@ -249,7 +260,12 @@ int gemv32(const Gv32Args& a, hipStream_t st) {
     auto lds_of = [](int nt, int nw) { return (size_t)nw * nt * 16 * 64 * sizeof(float); };
     // (four tiles per block - the A image read once per 128 columns - measured slower: 14.0 / 29.1 us against 11.5 / 12.9 for
     // gate/up and down alone, 63.0 against 61.6 ms per pipelined step)
-    if (tiles >= nt2_from && KS == 1) {
+    if (a.W_lo) {
+        // two weight planes per fragment: fewer fragments in flight per wave so that both planes' registers fit
+        if (tiles >= nt2_from && KS == 1) hipLaunchKernelGGL((gemv32_k<2, 4, 3, true>), dim3(cdiv(tiles, 2), 1, Z), dim3(256), lds_of(2, 4), st, a);
+        else if (tiles < nw8_below && KS == 1) hipLaunchKernelGGL((gemv32_k<1, 8, 4, true>), dim3(tiles, 1, Z), dim3(512), lds_of(1, 8), st, a);
+        else hipLaunchKernelGGL((gemv32_k<1, 4, 5, true>), dim3(tiles, KS, Z), dim3(256), lds_of(1, 4), st, a);
+    } else if (tiles >= nt2_from && KS == 1) {
         hipLaunchKernelGGL((gemv32_k<2, 4, 7>), dim3(cdiv(tiles, 2), 1, Z), dim3(256), lds_of(2, 4), st, a);
     } else if (tiles < nw8_below && KS == 1) {
         hipLaunchKernelGGL((gemv32_k<1, 8, 7>), dim3(tiles, 1, Z), dim3(512), lds_of(1, 8), st, a);

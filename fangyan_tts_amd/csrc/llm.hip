@@ -22,6 +22,9 @@ struct LlmLayerW {
     float *bqkv, *ln1, *ln2;
     // row-major bf16 copies [N][K] for the prefill GEMMs (many rows: the 8-row GEMV form would re-stream the weights per group)
     bf16_t *rqkv = nullptr, *ro = nullptr, *rgu = nullptr, *rd = nullptr;
+    // exact-weights mode (weight_planes == 2): the lo planes bf16(w - bf16(w)) of all of the above, same layouts
+    bf16_t *wqkv_lo = nullptr, *wo_lo = nullptr, *wgu_lo = nullptr, *wd_lo = nullptr;
+    bf16_t *rqkv_lo = nullptr, *ro_lo = nullptr, *rgu_lo = nullptr, *rd_lo = nullptr;
 };
 
 struct fy_llm {
@@ -31,6 +34,13 @@ struct fy_llm {
     std::vector<LlmLayerW> L;
     float *norm_w = nullptr, *speech_emb = nullptr, *inv_freq = nullptr;
     bf16_t *w_head = nullptr, *embed_tokens = nullptr;
+    // How the matrices are stored.  1: one bf16 plane (exact for bf16-representable weights - rounds 1-4's only form).  2: two planes
+    // w = hi + lo (16+ mantissa bits; a general fp32 checkpoint such as llm.pt, cli/model.py:65-73, keeps its values to 2^-17
+    // relative - below the fp32 reference's own summation-order noise) and embed_tokens in fp32.  cfg.weight_planes = 0 picks 2
+    // exactly when some matrix element is not bf16-representable.
+    int planes = 1;
+    bf16_t* w_head_lo = nullptr;
+    float* embed_tokens_f32 = nullptr;
     float *Kc = nullptr, *Vc = nullptr;            // [layers][max_batch][kv_heads][max_ctx][64]
     float *h, *xn, *qkv, *ao, *act, *hb, *logits, *partial, *logp_keep;
     bf16_t* act_split = nullptr;                     // SwiGLU output as three bf16 planes per 8 rows: [rows/8][24][inter]
@@ -70,16 +80,19 @@ extern "C" void fy_llm_default_config(fy_llm_config* c) {
     memset(c, 0, sizeof(*c));
     c->hidden = 896; c->layers = 24; c->q_heads = 14; c->kv_heads = 2; c->head_dim = 64; c->inter = 4864;
     c->vocab = 151936; c->speech_tokens = 6561; c->rms_eps = 1e-6f; c->rope_theta = 1e6f;
+    c->weight_planes = 0;
 }
 
 __constant__ int c_silent[11] = {1, 2, 28, 29, 55, 248, 494, 2241, 2242, 2322, 2323};   // cli/model.py:414
 
 // ---- kernels -------------------------------------------------------------------------------------------
 // lm_input rows (llm.py:728-740): src = id | kind<<30, kind 0 = embed_tokens (bf16), 1 = speech_embedding (fp32)
-__global__ void embed_rows_k(const int* __restrict__ src, const bf16_t* __restrict__ etok, const float* __restrict__ semb, float* __restrict__ h, int H) {
+// (etok32 != null: the text embedding kept in fp32 - the exact-weights mode)
+__global__ void embed_rows_k(const int* __restrict__ src, const bf16_t* __restrict__ etok, const float* __restrict__ etok32, const float* __restrict__ semb,
+                             float* __restrict__ h, int H) {
     int r = blockIdx.x, s = src[r], id = s & 0x3FFFFFFF, kind = s >> 30;
     for (int c = threadIdx.x; c < H; c += blockDim.x)
-        h[(long)r * H + c] = kind ? semb[(long)id * H + c] : bf16_to_f32(etok[(long)id * H + c]);
+        h[(long)r * H + c] = kind ? semb[(long)id * H + c] : (etok32 ? etok32[(long)id * H + c] : bf16_to_f32(etok[(long)id * H + c]));
 }
 
 // Qwen2RMSNorm: w * (x * rsqrt(mean(x^2) + eps)).  One wave per row.
@@ -474,6 +487,26 @@ static int copy_f32(fy_llm* l, const float* src, size_t n, float** dst, hipStrea
     return FY_OK;
 }
 
+// dst = src - float(bf16(src)): what one bf16 plane loses (its own bf16 rounding is the lo plane)
+__global__ void bf16_residual_k(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * 256UL + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i] - bf16_to_f32(f32_to_bf16(src[i]));
+}
+// *count += number of elements that are not bf16-representable
+__global__ void bf16_inexact_k(const float* __restrict__ src, size_t n, unsigned long long* __restrict__ count) {
+    unsigned long long c = 0;
+    for (size_t i = blockIdx.x * 256UL + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c += bf16_to_f32(f32_to_bf16(src[i])) != src[i];
+    c += __shfl_xor(c, 32, 64); c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 8, 64); c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 1, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+static unsigned grid_for(size_t n) { return (unsigned)std::min<size_t>(8192, (n + 255) / 256); }
+// the lo planes of a matrix src [N][K] (tmp: N*K floats of scratch): fragment order and / or row-major
+static int lo_planes(fy_llm* l, const float* src, float* tmp, int N, int K, bf16_t** packed, bf16_t** rowmajor, hipStream_t st) {
+    hipLaunchKernelGGL(bf16_residual_k, dim3(grid_for((size_t)N * K)), dim3(256), 0, st, src, tmp, (size_t)N * K);
+    if (packed) FY_TRY(to_packed(l, tmp, N, K, packed, st));
+    if (rowmajor) FY_TRY(to_bf16(l, tmp, (size_t)N * K, rowmajor, st));
+    return FY_OK;
+}
+
 // rows (gate_i, up_i) interleaved so one wave owns both halves of a SwiGLU pair
 __global__ void interleave_gu_k(const float* __restrict__ g, const float* __restrict__ u, float* __restrict__ out, int inter, int H) {
     long n = (long)2 * inter * H;
@@ -510,7 +543,45 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
     l->L.resize(c.layers);
     TRYC(l->pool.alloc(&l->Kc, (size_t)c.layers * l->cache_layer()));
     TRYC(l->pool.alloc(&l->Vc, (size_t)c.layers * l->cache_layer()));
-    {
+    if (c.weight_planes != 0 && c.weight_planes != 1 && c.weight_planes != 2) {
+        fy_set_error("fy_llm_create: weight_planes must be 0 (choose), 1 or 2, not %d", c.weight_planes);
+        return fail(FY_ERR_ARG);
+    }
+    l->planes = c.weight_planes == 2 ? 2 : 1;
+    if (c.weight_planes == 0) {
+        // one pass over the matrices: does bf16 storage lose anything?  (synthetic parity weights: no; a real checkpoint: yes)
+        unsigned long long* cnt = nullptr;
+        TRYC(l->pool.alloc(&cnt, (size_t)2));
+        bool ok = hipMemsetAsync(cnt, 0, 16, st) == hipSuccess;
+        auto scan = [&](const std::string& name, long rows, long cols) {
+            const float* w = W.get(name, {rows, cols});
+            if (!w) return false;
+            hipLaunchKernelGGL(bf16_inexact_k, dim3(grid_for((size_t)rows * cols)), dim3(256), 0, st, w, (size_t)rows * cols, cnt);
+            return true;
+        };
+        for (int i = 0; i < c.layers && ok; ++i) {
+            const std::string p = P + "layers." + std::to_string(i) + ".";
+            ok = scan(p + "self_attn.q_proj.weight", Q, H) && scan(p + "self_attn.k_proj.weight", KV, H) && scan(p + "self_attn.v_proj.weight", KV, H) &&
+                 scan(p + "self_attn.o_proj.weight", H, Q) && scan(p + "mlp.gate_proj.weight", I, H) && scan(p + "mlp.up_proj.weight", I, H) &&
+                 scan(p + "mlp.down_proj.weight", H, I);
+        }
+        ok = ok && scan("llm_decoder.weight", NS, H) && scan(P + "embed_tokens.weight", c.vocab, H);
+        unsigned long long n_inexact = 0;
+        if (!ok) return fail(FY_ERR_WEIGHT);
+        if (hipMemcpyAsync(&n_inexact, cnt, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            fy_set_error("fy_llm_create: weight scan failed");
+            return fail(FY_ERR_HIP);
+        }
+        l->planes = n_inexact ? 2 : 1;
+    }
+    const bool xw = l->planes == 2;
+    if (const char* e = getenv("FY_LLM_GEMV32")) l->gv32 = atoi(e) != 0;
+    if (H % 32 != 0 || I % 16 != 0 || H / 32 > 32) l->gv32 = false;
+    if (xw && !l->gv32) {
+        fy_set_error("fy_llm_create: two weight planes need the 32-row products (hidden %% 32 == 0, inter %% 16 == 0, hidden <= 1024; FY_LLM_GEMV32 unset)");
+        return fail(FY_ERR_ARG);
+    }
+    if (!xw) {       // the 8-row persistent step keeps a whole layer of weights in registers: one plane only
         DecodeShape ds;
         ds.H = H; ds.I = I; ds.Hq = c.q_heads; ds.Hk = c.kv_heads; ds.layers = c.layers; ds.NS = NS; ds.max_ctx = max_ctx; ds.mb = max_batch; ds.eps = c.rms_eps;
         if (decode_supported(ds)) TRYC(decode_create(&l->dec, ds, st));
@@ -548,6 +619,17 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
         if (rc2 == FY_OK) rc2 = to_bf16(l, tmpg, (size_t)2 * I * H, &k.rgu, st);
         if (rc2 == FY_OK) rc2 = to_bf16(l, ow, (size_t)H * Q, &k.ro, st);
         if (rc2 == FY_OK) rc2 = to_bf16(l, dw, (size_t)H * I, &k.rd, st);
+        if (rc2 == FY_OK && xw) {
+            // the lo planes (scratch: 2 I H floats hold the residual of any of the four matrices)
+            float* scratch = nullptr;
+            if (hipMalloc(&scratch, (size_t)2 * I * H * sizeof(float)) != hipSuccess) { fy_set_error("fy_llm_create: out of memory"); rc2 = FY_ERR_HIP; }
+            if (rc2 == FY_OK) rc2 = lo_planes(l, tmp, scratch, Q + 2 * KV, H, &k.wqkv_lo, &k.rqkv_lo, st);
+            if (rc2 == FY_OK) rc2 = lo_planes(l, tmpg, scratch, 2 * I, H, &k.wgu_lo, &k.rgu_lo, st);
+            if (rc2 == FY_OK) rc2 = lo_planes(l, ow, scratch, H, Q, &k.wo_lo, &k.ro_lo, st);
+            if (rc2 == FY_OK) rc2 = lo_planes(l, dw, scratch, H, I, &k.wd_lo, &k.rd_lo, st);
+            (void)hipStreamSynchronize(st);
+            if (scratch) (void)hipFree(scratch);
+        }
         if (rc2 == FY_OK && l->dec) {
             DecodeLayerSrc ds;
             ds.wqkv = tmp; ds.wo = ow; ds.wgu = tmpg; ds.wd = dw; ds.bqkv = k.bqkv; ds.ln1 = n1; ds.ln2 = n2;
@@ -571,7 +653,15 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
         TRYC(to_packed(l, hw, NS, H, &l->w_head, st));
         if (l->dec) TRYC(decode_pack_head(l->dec, hw, nw, st));
         TRYC(copy_f32(l, sw, (size_t)NS * H, &l->speech_emb, st));
-        TRYC(to_bf16(l, ew, (size_t)c.vocab * H, &l->embed_tokens, st));
+        if (xw) {
+            float* scratch = nullptr;
+            if (hipMalloc(&scratch, (size_t)NS * H * sizeof(float)) != hipSuccess) { fy_set_error("fy_llm_create: out of memory"); return fail(FY_ERR_HIP); }
+            int rc3 = lo_planes(l, hw, scratch, NS, H, &l->w_head_lo, nullptr, st);
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(scratch);
+            TRYC(rc3);
+            TRYC(copy_f32(l, ew, (size_t)c.vocab * H, &l->embed_tokens_f32, st));
+        } else TRYC(to_bf16(l, ew, (size_t)c.vocab * H, &l->embed_tokens, st));
     }
     {
         std::vector<float> inv(32);
@@ -586,8 +676,6 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
     const size_t R = l->max_rows, B = max_batch;
     TRYC(l->pool.alloc(&l->h, R * H)); TRYC(l->pool.alloc(&l->xn, R * H)); TRYC(l->pool.alloc(&l->qkv, R * l->qkv_dim()));
     TRYC(l->pool.alloc(&l->ao, R * H)); TRYC(l->pool.alloc(&l->act, (size_t)16)); TRYC(l->pool.alloc(&l->hb, B * H));
-    if (const char* e = getenv("FY_LLM_GEMV32")) l->gv32 = atoi(e) != 0;
-    if (H % 32 != 0 || I % 16 != 0 || H / 32 > 32) l->gv32 = false;
     // rows the 8- / 32-row products ever see: the tiled GEMMs take a prefill from prefill_gemm_rows on (when they apply at all)
     const size_t Rg = (l->prefill_gemm && H % 64 == 0 && I % 64 == 0) ? std::min<size_t>(R, std::max<size_t>(B, (size_t)l->prefill_gemm_rows)) : R;
     if (l->gv32) {
@@ -603,7 +691,7 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
             return fail(FY_ERR_HIP);
         }
     } else TRYC(l->pool.alloc(&l->act_split, ((R + 7) / 8) * 24 * (size_t)I));
-    if (l->gv32 && max_batch > 8) {
+    if (l->gv32) {
         // the few-CU persistent step for 9 .. 32 sequences shares the per-operation path's weights, images and scratch
         Dec32Shape s32;
         s32.H = H; s32.I = I; s32.Hq = c.q_heads; s32.Hk = c.kv_heads; s32.layers = c.layers; s32.NS = NS; s32.max_ctx = max_ctx; s32.mb = max_batch; s32.eps = c.rms_eps;
@@ -613,18 +701,19 @@ extern "C" int fy_llm_create(fy_llm** out, const fy_llm_config* cfg, const fy_te
                 const LlmLayerW& k = l->L[i];
                 ly[i].wqkv = k.wqkv; ly[i].wo = k.wo; ly[i].wgu = k.wgu; ly[i].wd = k.wd; ly[i].bqkv = k.bqkv; ly[i].ln1 = k.ln1; ly[i].ln2 = k.ln2;
                 ly[i].Kc = l->Kc + (size_t)i * l->cache_layer(); ly[i].Vc = l->Vc + (size_t)i * l->cache_layer();
+                ly[i].wqkv_lo = k.wqkv_lo; ly[i].wo_lo = k.wo_lo; ly[i].wgu_lo = k.wgu_lo; ly[i].wd_lo = k.wd_lo;
             }
-            TRYC(decode32_create(&l->dec32, s32, ly.data(), l->w_head, l->norm_w, st));
+            TRYC(decode32_create(&l->dec32, s32, ly.data(), l->w_head, l->norm_w, st, l->w_head_lo));
         }
     }
     TRYC(l->pool.alloc(&l->logits, B * NS)); TRYC(l->pool.alloc(&l->partial, gemv_partial_floats((int)R, H, I) + 16));
     TRYC(l->pool.alloc(&l->counters, gemv_counter_ints((int)R, H, I) + 16));
     if (hipMemsetAsync(l->counters, 0, (gemv_counter_ints((int)R, H, I) + 16) * sizeof(int), st) != hipSuccess) { fy_set_error("fy_llm_create: memset failed"); return fail(FY_ERR_HIP); }
     TRYC(l->pool.alloc(&l->logp_keep, (size_t)FY_LLM_KEEP_LOGP * B * NS));
-    TRYC(l->pool.alloc(&l->gu, R * 2 * (size_t)I)); TRYC(l->pool.alloc(&l->actf, R * (size_t)I)); TRYC(l->pool.alloc(&l->ones, (size_t)H));
+    TRYC(l->pool.alloc(&l->gu, R * 2 * (size_t)I)); TRYC(l->pool.alloc(&l->actf, R * (size_t)I)); TRYC(l->pool.alloc(&l->ones, (size_t)std::max(2 * I, l->qkv_dim())));
     TRYC(l->pool.alloc(&l->pl3, 3 * R * (size_t)std::max(H, I)));
     l->prefill_ring = !(getenv("FY_LLM_PREFILL_RING") && atoi(getenv("FY_LLM_PREFILL_RING")) == 0);
-    hipLaunchKernelGGL(fill_k, dim3(cdiv(H, 256)), dim3(256), 0, st, l->ones, 1.0f, H);
+    hipLaunchKernelGGL(fill_k, dim3(cdiv(std::max(2 * I, l->qkv_dim()), 256)), dim3(256), 0, st, l->ones, 1.0f, std::max(2 * I, l->qkv_dim()));
     TRYC(l->pool.alloc(&l->row_seq, R)); TRYC(l->pool.alloc(&l->row_pos, R)); TRYC(l->pool.alloc(&l->row_src, R));
     TRYC(l->pool.alloc(&l->last_row, B)); TRYC(l->pool.alloc(&l->st, 8 * B)); TRYC(l->pool.alloc(&l->seq_ids, B));
     {
@@ -672,30 +761,43 @@ static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, 
             // planes once by a small kernel instead of by every column tile's workgroup, and the K loop is the DiT linears'.
             const bool ring = l->prefill_ring && gemm_exact3_supported(QKV, H) && gemm_exact3_supported(H, H) && gemm_exact3_supported(2 * I, H) && gemm_exact3_supported(H, I);
             // exact(A, K, W, N, e): A == nullptr means the producer already left the planes in pl3
-            auto exact = [&](const float* A, int K, const bf16_t* W, int N, GemmEpi& e) -> int {
-                if (!ring) return gemm_f32a_exact(A, K, W, R, N, K, e, st);
+            // W_lo (exact-weights mode): the product is W a + W_lo a - a second pass that ADDS into the first one's output (the gated
+            // residual form with a gate of ones; every epilogue here is linear in the product)
+            auto exact = [&](const float* A, int K, const bf16_t* W, const bf16_t* W_lo, int N, GemmEpi& e) -> int {
+                GemmEpi e2;
+                if (W_lo) {
+                    e2.mode = EPI_GATE_RESID; e2.gate = l->ones; e2.ldc = e.ldc;
+                    e2.resid = e.mode == EPI_GATE_RESID ? e.resid : (float*)e.out;
+                }
+                if (!ring) {
+                    FY_TRY(gemm_f32a_exact(A, K, W, R, N, K, e, st));
+                    return W_lo ? gemm_f32a_exact(A, K, W_lo, R, N, K, e2, st) : FY_OK;
+                }
                 bf16_t *p0 = l->pl3, *p1 = p0 + (size_t)R * K, *p2 = p1 + (size_t)R * K;
                 if (A) FY_TRY(split3_planes(A, K, R, K, p0, p1, p2, st));
                 e.a_lo = p1; e.a_lo2 = p2;
-                return gemm_exact3(p0, K, W, R, N, K, e, st);
+                FY_TRY(gemm_exact3(p0, K, W, R, N, K, e, st));
+                if (!W_lo) return FY_OK;
+                e2.a_lo = p1; e2.a_lo2 = p2;
+                return gemm_exact3(p0, K, W_lo, R, N, K, e2, st);
             };
             hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln1, l->xn, R, H, c.rms_eps, ring ? l->pl3 : nullptr);
             GemmEpi q;
             q.bias = k.bqkv; q.out = l->qkv; q.out_bf16 = 0; q.ldc = QKV;
-            FY_TRY(exact(ring ? nullptr : l->xn, H, k.rqkv, QKV, q));
+            FY_TRY(exact(ring ? nullptr : l->xn, H, k.rqkv, k.rqkv_lo, QKV, q));
             hipLaunchKernelGGL(rope_kv_k, dim3(R), dim3(256), 0, st, l->qkv, Kc, Vc, row_seq, row_pos, l->inv_freq, c.q_heads, c.kv_heads, l->max_ctx);
             FY_TRY(llm_attention(l->qkv, QKV, Kc, Vc, row_seq, row_pos, l->ao, H, R, c.q_heads, c.kv_heads, l->max_ctx, st));
             GemmEpi o;
             o.mode = EPI_GATE_RESID; o.resid = l->h; o.gate = l->ones; o.ldc = H;
-            FY_TRY(exact(l->ao, H, k.ro, H, o));
+            FY_TRY(exact(l->ao, H, k.ro, k.ro_lo, H, o));
             hipLaunchKernelGGL(rmsnorm_k, dim3(cdiv(R, 4)), dim3(256), 0, st, l->h, k.ln2, l->xn, R, H, c.rms_eps, ring ? l->pl3 : nullptr);
             GemmEpi g;
             g.out = l->gu; g.out_bf16 = 0; g.ldc = 2 * I;
-            FY_TRY(exact(ring ? nullptr : l->xn, H, k.rgu, 2 * I, g));
+            FY_TRY(exact(ring ? nullptr : l->xn, H, k.rgu, k.rgu_lo, 2 * I, g));
             hipLaunchKernelGGL(swiglu_rows_k, dim3(std::min(4096, cdiv(R * I, ring ? 512 : 256))), dim3(256), 0, st, l->gu, l->actf, (long)R * I, I, ring ? l->pl3 : nullptr);
             GemmEpi d;
             d.mode = EPI_GATE_RESID; d.resid = l->h; d.gate = l->ones; d.ldc = H;
-            FY_TRY(exact(ring ? nullptr : l->actf, I, k.rd, H, d));
+            FY_TRY(exact(ring ? nullptr : l->actf, I, k.rd, k.rd_lo, H, d));
             continue;
         }
         if (l->gv32) {
@@ -703,7 +805,7 @@ static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, 
             // decode: the sampler), every product's epilogue leaves what the next one reads
             const int NP = H / 32;
             Gv32Args q;
-            q.W = k.wqkv; q.img = l->img_h; q.R = R; q.N = QKV; q.K = H; q.ssq = l->ssq; q.n_ssq = NP; q.eps = c.rms_eps; q.bias = k.bqkv;
+            q.W = k.wqkv; q.W_lo = k.wqkv_lo; q.img = l->img_h; q.R = R; q.N = QKV; q.K = H; q.ssq = l->ssq; q.n_ssq = NP; q.eps = c.rms_eps; q.bias = k.bqkv;
             q.y = l->qkv; q.ldy = QKV;
             FY_TRY(gemv32(q, st));
             if (decode) {
@@ -714,15 +816,15 @@ static int llm_layers(fy_llm* l, int R, const int* row_seq, const int* row_pos, 
                 FY_TRY(gv32_split_rows(l->ao, H, R, H, nullptr, l->img_ao, nullptr, st));
             }
             Gv32Args o;
-            o.W = k.wo; o.img = l->img_ao; o.R = R; o.N = H; o.K = H; o.mode = GV32_ADD_IMG; o.y = l->h; o.ldy = H;
+            o.W = k.wo; o.W_lo = k.wo_lo; o.img = l->img_ao; o.R = R; o.N = H; o.K = H; o.mode = GV32_ADD_IMG; o.y = l->h; o.ldy = H;
             o.ln_next = k.ln2; o.img_out = l->img_h; o.ssq_out = l->ssq;
             FY_TRY(gemv32(o, st));
             Gv32Args g;
-            g.W = k.wgu; g.img = l->img_h; g.R = R; g.N = 2 * I; g.K = H; g.ssq = l->ssq; g.n_ssq = NP; g.eps = c.rms_eps;
+            g.W = k.wgu; g.W_lo = k.wgu_lo; g.img = l->img_h; g.R = R; g.N = 2 * I; g.K = H; g.ssq = l->ssq; g.n_ssq = NP; g.eps = c.rms_eps;
             g.mode = GV32_SWIGLU_IMG; g.img_out = l->img_act;
             FY_TRY(gemv32(g, st));
             Gv32Args d;
-            d.W = k.wd; d.img = l->img_act; d.R = R; d.N = H; d.K = I; d.mode = GV32_ADD_IMG; d.y = l->h; d.ldy = H;
+            d.W = k.wd; d.W_lo = k.wd_lo; d.img = l->img_act; d.R = R; d.N = H; d.K = I; d.mode = GV32_ADD_IMG; d.y = l->h; d.ldy = H;
             d.ln_next = i + 1 < c.layers ? l->L[i + 1].ln1 : l->norm_w; d.img_out = l->img_h; d.ssq_out = l->ssq;
             d.partial = l->part32; d.counters = l->cnt32;
             FY_TRY(gemv32(d, st));
@@ -764,7 +866,7 @@ static int llm_head_and_sample(fy_llm* l, int B, const float* rows, int32_t* out
     if (l->gv32) {
         if (!have_img) FY_TRY(gv32_split_rows(rows, H, B, H, l->norm_w, l->img_h, l->ssq, st));
         Gv32Args a;
-        a.W = l->w_head; a.img = l->img_h; a.R = B; a.N = NS; a.K = H; a.ssq = l->ssq; a.n_ssq = H / 32; a.eps = c.rms_eps; a.y = l->logits; a.ldy = NS;
+        a.W = l->w_head; a.W_lo = l->w_head_lo; a.img = l->img_h; a.R = B; a.N = NS; a.K = H; a.ssq = l->ssq; a.n_ssq = H / 32; a.eps = c.rms_eps; a.y = l->logits; a.ldy = NS;
         FY_TRY(gemv32(a, st));
         return llm_sample(l, B, out_ids, out_ld, keep_step, st);
     }
@@ -866,7 +968,7 @@ extern "C" int fy_llm_begin(fy_llm* l, const int32_t* text_ids, const int32_t* n
     FY_CHECK(R <= l->max_rows, FY_ERR_ARG, "fy_llm_generate: %d prefill rows exceed the workspace (%d)", R, l->max_rows);
     HIP_TRY(hipMemcpyAsync(l->row_src, src.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));                        // src dies with this frame
-    hipLaunchKernelGGL(embed_rows_k, dim3(R), dim3(256), 0, st, l->row_src, l->embed_tokens, l->speech_emb, l->h, H);
+    hipLaunchKernelGGL(embed_rows_k, dim3(R), dim3(256), 0, st, l->row_src, l->embed_tokens, l->embed_tokens_f32, l->speech_emb, l->h, H);
     return llm_begin_rows(l, rows.data(), min_len, max_len, B, out_ids, out_ld, st);
 }
 
@@ -909,7 +1011,7 @@ extern "C" int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t
     unsigned dec_status = 0;
     int step = l->step_next;
     const bool persistent = l->dec && l->decode_mode == 1 && B <= 8;
-    const bool persistent32 = !persistent && l->dec32 && l->decode_mode == 1 && B <= 32;
+    const bool persistent32 = !persistent && l->dec32 && (l->decode_mode == 1 || l->decode_mode == 2) && B <= 32;
     auto read_done = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(done.data(), l->st + 3 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
         // only a call that used the persistent step looks at (and clears) its time-out word: a time-out is reported once,
@@ -1016,9 +1118,16 @@ extern "C" int fy_debug_decode32_stamps(fy_llm* l, unsigned long long* out, int3
 }
 
 extern "C" int fy_llm_set_decode_mode(fy_llm* l, int32_t mode) {
-    FY_CHECK(l && (mode == 0 || mode == 1), FY_ERR_ARG, "fy_llm_set_decode_mode: mode must be 0 (one launch per operation) or 1 (persistent step)");
+    FY_CHECK(l && (mode == 0 || mode == 1 || mode == 2), FY_ERR_ARG,
+             "fy_llm_set_decode_mode: mode must be 0 (one launch per operation), 1 (persistent step) or 2 (the few-CU persistent step only)");
     l->decode_mode = mode;
     return FY_OK;
 }
 
-extern "C" int fy_llm_decode_mode(const fy_llm* l) { return l && (l->dec || l->dec32) && l->decode_mode == 1 ? 1 : 0; }
+extern "C" int fy_llm_decode_mode(const fy_llm* l) {
+    if (!l) return 0;
+    if (l->decode_mode == 1) return (l->dec || l->dec32) ? 1 : 0;
+    return l->decode_mode == 2 && l->dec32 ? 2 : 0;
+}
+
+extern "C" int fy_llm_weight_planes(const fy_llm* l) { return l ? l->planes : 0; }

@@ -968,9 +968,8 @@ int decode_pack_head(DecodePlan* p, const float* w_head, const float* norm_w, hi
 }
 
 // Two persistent grids that are each only partly resident would wait for each other's CUs forever (until the spin bound),
-// so decode launches of ALL handles of the process are chained: a launch waits (on the GPU) for the previous one.
-static std::mutex g_chain_mu;
-static hipEvent_t g_chain_ev = nullptr;
+// so persistent launches of ALL handles of a device - this kernel's and llm_decode32_k's - are chained (runtime.h:
+// persistent_chain): a launch waits (on the GPU) for the previous one.
 
 int decode_step(DecodePlan* p, int B, float* h, const int* st_block, const float* inv_freq, float* logits, hipStream_t stream) {
     FY_CHECK(p && B >= 1 && B <= 8 && h && st_block && inv_freq && logits, FY_ERR_ARG, "decode_step: bad arguments");
@@ -985,13 +984,14 @@ int decode_step(DecodePlan* p, int B, float* h, const int* st_block, const float
     // bench.py's roofline leg: algorithmic bytes of a token step = every bf16 weight once (the launch streams nothing twice)
     const double wbytes = 2.0 * ((double)s.layers * ((double)s.qkv() * s.H + (double)s.H * s.H + 3.0 * s.I * s.H) + (double)s.NS * s.H);
     ProfScope prof("llm_decode", wbytes, stream);
-    std::lock_guard<std::mutex> lk(g_chain_mu);
-    if (!g_chain_ev) HIP_TRY(hipEventCreateWithFlags(&g_chain_ev, hipEventDisableTiming));
-    else HIP_TRY(hipStreamWaitEvent(stream, g_chain_ev, 0));
+    PersistentChain& chain = persistent_chain();
+    std::lock_guard<std::mutex> lk(chain.mu);
+    if (!chain.ev) HIP_TRY(hipEventCreateWithFlags(&chain.ev, hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(stream, chain.ev, 0));
     if (p->kind == 1) hipLaunchKernelGGL(llm_decode_k<CfgFull>, dim3(p->G), dim3(512), p->lds, stream, a);
     else hipLaunchKernelGGL(llm_decode_k<CfgTiny>, dim3(p->G), dim3(512), p->lds, stream, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(g_chain_ev, stream));
+    HIP_TRY(hipEventRecord(chain.ev, stream));
     return FY_OK;
 }
 

@@ -10,6 +10,8 @@ struct Dec32Layer {
     const bf16_t *wqkv, *wo, *wgu, *wd;       // gemv_pack fragment order [N/32][K/16][64][8]; wgu rows (gate_i, up_i) interleaved
     const float *bqkv, *ln1, *ln2;
     float *Kc, *Vc;                           // this layer's cache [seq][Hk][max_ctx][64]
+    // exact-weights mode (gemv32.h: Gv32Args::W_lo): the lo planes bf16(w - bf16(w)) in the same order; all null = one plane
+    const bf16_t *wqkv_lo = nullptr, *wo_lo = nullptr, *wgu_lo = nullptr, *wd_lo = nullptr;
 };
 
 struct Dec32Shape {
@@ -22,7 +24,9 @@ struct Dec32Plan;
 
 bool decode32_supported(const Dec32Shape& s);
 // layers: host array of s.layers entries (device pointers); copied to the device
-int decode32_create(Dec32Plan** out, const Dec32Shape& s, const Dec32Layer* layers, const bf16_t* w_head, const float* norm_w, hipStream_t st);
+// w_head_lo: the head's lo plane (exact-weights mode; then every layer's *_lo pointers must be set too), or null
+int decode32_create(Dec32Plan** out, const Dec32Shape& s, const Dec32Layer* layers, const bf16_t* w_head, const float* norm_w, hipStream_t st,
+                    const bf16_t* w_head_lo = nullptr);
 void decode32_destroy(Dec32Plan* p);
 int decode32_groups(const Dec32Plan* p);
 // One token step for sequences 0 .. B-1 (8 < B <= 32 is what it is for; any 1 <= B <= 32 works).  In: h (fp32 [mb][H], the rows the

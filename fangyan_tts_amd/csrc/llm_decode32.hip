@@ -33,6 +33,7 @@ struct D32Args {
     const Dec32Layer* layers;
     int n_layers;
     const bf16_t* w_head;
+    const bf16_t* w_head_lo;               // exact-weights mode (XW): the head's lo plane
     const float* norm_w;
     int R, G, TG, H, I, QKV, Hq, Hk, NS, max_ctx;
     float eps;
@@ -162,6 +163,14 @@ __device__ __forceinline__ void d32_mfma(const d32_frag (&A)[FW][3], const d32_f
     for (int u = 0; u < FW; ++u)
 #pragma unroll
         for (int p = 0; p < 3; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[u][p], b[u], acc, 0, 0, 0);
+}
+// exact-weights mode: the lo-plane fragments of the same tile meet the two leading operand planes and continue the accumulator
+template <int FW>
+__device__ __forceinline__ void d32_mfma_lo(const d32_frag (&A)[FW][3], const d32_frag (&b)[FW], f32x16& acc) {
+#pragma unroll
+    for (int u = 0; u < FW; ++u)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[u][p], b[u], acc, 0, 0, 0);
 }
 __device__ __forceinline__ void d32_park(float* red, int buf, int wid, int lane, const f32x16& acc) {
     float* p = red + ((buf * 8 + wid) * 16) * 64 + lane;
@@ -347,8 +356,10 @@ __device__ __forceinline__ void d32_attention_unit(const D32Args& a, const Dec32
 // registers, the weights a tile ahead (b0 arrives already requested: the hand-off's prefetch), the eight waves' partial tiles through
 // LDS; pre(tile, item) may request what the epilogue needs (the residual) before the products; epi(tile, item, sum, pre's value)
 // runs on threads 0 .. 255.
-template <int FW, class Pre, class Epi>
-__device__ __forceinline__ void d32_product(const bf16_t* W, const bf16_t* img, int K16, int first, int stride, int n_tiles, float* red, int tid, int wid, int lane,
+// XW (exact-weights mode): a tile's weights are W + W_lo; the two planes take turns in the SAME registers - the hi fragments' products
+// run while the lo fragments fly, the lo fragments' while the next tile's hi fragments fly - so the register budget is the one-plane form's.
+template <int FW, bool XW, class Pre, class Epi>
+__device__ __forceinline__ void d32_product(const bf16_t* W, const bf16_t* W_lo, const bf16_t* img, int K16, int first, int stride, int n_tiles, float* red, int tid, int wid, int lane,
                                             d32_frag (&b0)[FW], Pre pre, Epi epi) {
     if (first >= n_tiles) return;
     d32_frag A[FW][3], b1[FW];
@@ -356,10 +367,17 @@ __device__ __forceinline__ void d32_product(const bf16_t* W, const bf16_t* img, 
     d32_load_image<FW>(img, K16, A, wid, lane);
     int buf = 0;
     for (int t = first; t < n_tiles; t += stride, buf ^= 1) {
-        d32_load_w<FW>(W, min(t + stride, n_tiles - 1), K16, b1, wid, lane);        // unconditional (clamped): no copies at a join
+        if constexpr (XW) d32_load_w<FW>(W_lo, t, K16, b1, wid, lane);
+        else d32_load_w<FW>(W, min(t + stride, n_tiles - 1), K16, b1, wid, lane);        // unconditional (clamped): no copies at a join
         float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < 256) pv = pre(t, tid);
         d32_mfma<FW>(A, b0, acc);
+        if constexpr (XW) {
+#pragma unroll
+            for (int u = 0; u < FW; ++u) b0[u] = b1[u];
+            d32_load_w<FW>(W, min(t + stride, n_tiles - 1), K16, b1, wid, lane);
+            d32_mfma_lo<FW>(A, b0, acc);
+        }
         d32_park(red, buf, wid, lane, acc);
         __syncthreads();
         if (tid < 256) epi(t, tid, d32_combine(red, buf, tid), pv);
@@ -368,7 +386,7 @@ __device__ __forceinline__ void d32_product(const bf16_t* W, const bf16_t* img, 
     }
 }
 
-template <int FW, int TG>
+template <int FW, int TG, bool XW = false>
 __global__ __launch_bounds__(512) void llm_decode32_k(const D32Args a) {
     extern __shared__ __attribute__((aligned(16))) char d32_smem[];
     char* smem = d32_smem;
@@ -396,7 +414,7 @@ __global__ __launch_bounds__(512) void llm_decode32_k(const D32Args a) {
             const Dec32Layer ly = a.layers[L];
             const d32_rsrc rs_qkv = d32_desc(a.qkv, (long)32 * a.QKV * 4);
             if (g < NTQ) d32_rstd(a.ssq, NP, a.eps, H, rstd_s, tid_p);
-            d32_product<FW>(ly.wqkv, a.img_h, K16, g, G, NTQ, red, tid_p, wid_p, lane_p, bn, none4, [&](int t, int it, const float4& v, const float4&) {
+            d32_product<FW, XW>(ly.wqkv, ly.wqkv_lo, a.img_h, K16, g, G, NTQ, red, tid_p, wid_p, lane_p, bn, none4, [&](int t, int it, const float4& v, const float4&) {
                 const int r = it >> 3, n = t * 32 + (it & 7) * 4;
                 if (r < a.R) {
                     const float rs = rstd_s[r];
@@ -422,7 +440,7 @@ __global__ __launch_bounds__(512) void llm_decode32_k(const D32Args a) {
             D32_FRESH();
             const Dec32Layer ly = a.layers[L];
             const d32_rsrc rs_h = d32_desc(a.h, (long)32 * H * 4);
-            d32_product<FW>(ly.wo, a.img_ao, K16, g, G, NTO, red, tid_p, wid_p, lane_p, bn,
+            d32_product<FW, XW>(ly.wo, ly.wo_lo, a.img_ao, K16, g, G, NTO, red, tid_p, wid_p, lane_p, bn,
                             [&](int t, int it) { return (it >> 3) < a.R ? d32_ld4(rs_h, (long)(it >> 3) * H + t * 32 + (it & 7) * 4) : make_float4(0.f, 0.f, 0.f, 0.f); },
                             [&](int t, int it, const float4& v, const float4& y0) { d32_add_img(a, rs_h, t, it, v, y0, ly.ln2); });
         }
@@ -433,17 +451,22 @@ __global__ __launch_bounds__(512) void llm_decode32_k(const D32Args a) {
         {
             // wave w takes the down projection's column tiles w, w + 8, ... (at most four: hidden <= 1024), NB at a time with all of their
             // weight fragments in flight; the first batch is requested before the last gate/up tile's products
-            constexpr int NB = TG == 4 ? 4 : 2;
+            // (exact-weights mode: both planes of a batch are in flight together, so a batch is half as many tiles)
+            constexpr int NB = (TG == 4 ? 4 : 2) / (XW ? 2 : 1);
             D32_FRESH();
             const Dec32Layer ly = a.layers[L];
             d32_rstd(a.ssq, NP, a.eps, H, rstd_s, tid_p);
-            d32_frag wd[NB][TG];
+            d32_frag wd[NB][TG], wdl[XW ? NB : 1][TG];
             auto load_wd = [&](int i0) {
 #pragma unroll
                 for (int i = 0; i < NB; ++i) {
                     const int t = min(wid_p + 8 * (i0 + i), NTO - 1);
 #pragma unroll
                     for (int u = 0; u < TG; ++u) wd[i][u] = d32_ld_nt(ly.wd + ((long)t * K16I + (long)TG * g + u) * 512 + lane_p * 8);
+                    if constexpr (XW) {
+#pragma unroll
+                        for (int u = 0; u < TG; ++u) wdl[i][u] = d32_ld_nt(ly.wd_lo + ((long)t * K16I + (long)TG * g + u) * 512 + lane_p * 8);
+                    }
                 }
             };
             {
@@ -451,8 +474,13 @@ __global__ __launch_bounds__(512) void llm_decode32_k(const D32Args a) {
                 f32x16 acc;
                 d32_load_image<FW>(a.img_h, K16, A, wid_p, lane_p);
                 // one gate/up tile: products on bn, the waves' sums through LDS, SwiGLU of the 16 column pairs into the slice
-                auto tile = [&](int tl) {
-                    d32_mfma<FW>(A, bn, acc);
+                // (exact-weights mode: the gate/up weights are a stream of 2 TG half tiles - hi plane, lo plane, hi plane of the next
+                // tile, ... - through the same registers; an even half starts the accumulator, an odd one continues and finishes it)
+                auto tile = [&](int v) {
+                    const int tl = XW ? v >> 1 : v;
+                    if (XW && (v & 1)) d32_mfma_lo<FW>(A, bn, acc);
+                    else d32_mfma<FW>(A, bn, acc);
+                    if (XW && !(v & 1)) return;
                     d32_park(red, tl & 1, wid_p, lane_p, acc);
                     __syncthreads();
                     // waves 0-3 finish the even tiles, waves 4-7 the odd ones: the half that has no epilogue is already in the next tile's products
@@ -477,19 +505,24 @@ __global__ __launch_bounds__(512) void llm_decode32_k(const D32Args a) {
                 };
                 // weights two tiles ahead: a tile's turn (products, the trip through LDS, SwiGLU) is shorter than a trip to HBM
                 d32_frag b1[FW], b2[FW];
-                d32_load_w<FW>(ly.wgu, (long)TG * g + 1, K16, b1, wid_p, lane_p);
+                constexpr int NV = XW ? 2 * TG : TG;
+                auto vload = [&](int v, d32_frag (&b)[FW]) {
+                    if constexpr (XW) d32_load_w<FW>((v & 1) ? ly.wgu_lo : ly.wgu, (long)TG * g + (v >> 1), K16, b, wid_p, lane_p);
+                    else d32_load_w<FW>(ly.wgu, (long)TG * g + v, K16, b, wid_p, lane_p);
+                };
+                vload(1, b1);
 #pragma unroll 1
-                for (int tl = 0; tl + 2 < TG; ++tl) {
-                    d32_load_w<FW>(ly.wgu, (long)TG * g + tl + 2, K16, b2, wid_p, lane_p);
-                    tile(tl);
+                for (int v = 0; v + 2 < NV; ++v) {
+                    vload(v + 2, b2);
+                    tile(v);
 #pragma unroll
                     for (int u = 0; u < FW; ++u) { bn[u] = b1[u]; b1[u] = b2[u]; }
                 }
-                tile(TG - 2);
+                tile(NV - 2);
 #pragma unroll
                 for (int u = 0; u < FW; ++u) bn[u] = b1[u];
                 load_wd(0);                               // the down projection's first batch flies under the last tile
-                tile(TG - 1);
+                tile(NV - 1);
             }
             __syncthreads();                              // the slice is complete
             stamp();
@@ -510,6 +543,7 @@ __global__ __launch_bounds__(512) void llm_decode32_k(const D32Args a) {
                         for (int p = 0; p < 3; ++p) {
                             const d32_frag af = *reinterpret_cast<const d32_frag*>(slice + ((u * 3 + p) * 64 + lane_p) * 8);
                             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wd[i][u], acc, 0, 0, 0);
+                            if constexpr (XW) { if (p < 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wdl[i][u], acc, 0, 0, 0); }
                         }
                     if (t < NTO) {
                         const long dst = ((long)g * NTO + t) * 1024 + lane_p * 4;
@@ -568,7 +602,7 @@ __global__ __launch_bounds__(512) void llm_decode32_k(const D32Args a) {
     }
     // ================= head: logits = W_head (norm_w x h) * rstd =================
     if (g < NTH) d32_rstd(a.ssq, NP, a.eps, H, rstd_s, tid);
-    d32_product<FW>(a.w_head, a.img_h, K16, g, G, NTH, red, tid, wid, lane, bn, none4, [&](int t, int it, const float4& v, const float4&) {
+    d32_product<FW, XW>(a.w_head, a.w_head_lo, a.img_h, K16, g, G, NTH, red, tid, wid, lane, bn, none4, [&](int t, int it, const float4& v, const float4&) {
         const int r = it >> 3, n = t * 32 + (it & 7) * 4;
         if (r < a.R) {
             const float rs = rstd_s[r];
@@ -587,7 +621,7 @@ struct Dec32Plan {
     int G = 0, TG = 8, kind = 0;                 // kind = FW: 7 (hidden 896) or 2 (hidden 256)
     DevPool pool;
     Dec32Layer* layers = nullptr;
-    const bf16_t* w_head = nullptr;
+    const bf16_t *w_head = nullptr, *w_head_lo = nullptr;
     const float* norm_w = nullptr;
     float* part = nullptr;
     unsigned *flags = nullptr, *status = nullptr;
@@ -621,9 +655,16 @@ bool decode32_supported(const Dec32Shape& s) {
 
 int decode32_groups(const Dec32Plan* p) { return p ? p->G : 0; }
 
-int decode32_create(Dec32Plan** out, const Dec32Shape& s, const Dec32Layer* layers, const bf16_t* w_head, const float* norm_w, hipStream_t st) {
+int decode32_create(Dec32Plan** out, const Dec32Shape& s, const Dec32Layer* layers, const bf16_t* w_head, const float* norm_w, hipStream_t st,
+                    const bf16_t* w_head_lo) {
     FY_CHECK(out && layers && w_head && norm_w && decode32_supported(s), FY_ERR_ARG, "decode32_create: unsupported shape");
+    for (int i = 0; i < s.layers; ++i) {
+        const bool lo = layers[i].wqkv_lo && layers[i].wo_lo && layers[i].wgu_lo && layers[i].wd_lo;
+        const bool none = !layers[i].wqkv_lo && !layers[i].wo_lo && !layers[i].wgu_lo && !layers[i].wd_lo;
+        FY_CHECK(w_head_lo ? lo : none, FY_ERR_ARG, "decode32_create: layer %d: the lo planes must be given for every matrix and the head, or for none", i);
+    }
     Dec32Plan* p = new Dec32Plan();
+    p->w_head_lo = w_head_lo;
     p->s = s; p->TG = d32_tg(s); p->G = s.I / (16 * p->TG); p->kind = s.H / 16 / 8;
     p->w_head = w_head; p->norm_w = norm_w;
     auto fail = [&](int rc) { delete p; return rc; };
@@ -639,7 +680,8 @@ int decode32_create(Dec32Plan** out, const Dec32Shape& s, const Dec32Layer* laye
         fy_set_error("decode32_create: upload failed");
         return fail(FY_ERR_HIP);
     }
-    for (const void* fn : {(const void*)llm_decode32_k<7, 8>, (const void*)llm_decode32_k<7, 4>, (const void*)llm_decode32_k<2, 8>, (const void*)llm_decode32_k<2, 4>})
+    for (const void* fn : {(const void*)llm_decode32_k<7, 8>, (const void*)llm_decode32_k<7, 4>, (const void*)llm_decode32_k<2, 8>, (const void*)llm_decode32_k<2, 4>,
+                           (const void*)llm_decode32_k<7, 8, true>, (const void*)llm_decode32_k<7, 4, true>, (const void*)llm_decode32_k<2, 8, true>, (const void*)llm_decode32_k<2, 4, true>})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)D32_LDS) != hipSuccess) {
             fy_set_error("decode32_create: %d bytes of LDS refused", (int)D32_LDS);
             return fail(FY_ERR_HIP);
@@ -650,31 +692,37 @@ int decode32_create(Dec32Plan** out, const Dec32Shape& s, const Dec32Layer* laye
 
 void decode32_destroy(Dec32Plan* p) { delete p; }
 
-// like the 8-row persistent step, launches of ALL handles are chained: two partly resident grids would wait for each other
-static std::mutex g32_mu;
-static hipEvent_t g32_ev = nullptr;
+// like the 8-row persistent step - and behind the SAME event (runtime.h: persistent_chain) - launches of ALL handles are chained:
+// two partly resident grids, of either kernel, would wait for each other
 
 int decode32_step(Dec32Plan* p, int B, float* h, bf16_t* img_h, float* ssq, float* qkv, bf16_t* img_ao, const int* st_block,
                   const float* inv_freq, float* logits, hipStream_t stream) {
     FY_CHECK(p && B >= 1 && B <= 32 && h && img_h && ssq && qkv && img_ao && st_block && inv_freq && logits, FY_ERR_ARG, "decode32_step: bad arguments");
     const Dec32Shape& s = p->s;
     D32Args a;
-    a.layers = p->layers; a.n_layers = s.layers; a.w_head = p->w_head; a.norm_w = p->norm_w;
+    a.layers = p->layers; a.n_layers = s.layers; a.w_head = p->w_head; a.w_head_lo = p->w_head_lo; a.norm_w = p->norm_w;
     a.R = B; a.G = p->G; a.TG = p->TG; a.H = s.H; a.I = s.I; a.QKV = s.qkv(); a.Hq = s.Hq; a.Hk = s.Hk; a.NS = s.NS; a.max_ctx = s.max_ctx; a.eps = s.eps;
     a.h = h; a.img_h = img_h; a.ssq = ssq; a.qkv = qkv; a.img_ao = img_ao; a.part = p->part; a.logits = logits;
     a.st = st_block; a.inv_freq = inv_freq; a.flags = p->flags; a.epoch0 = p->epoch; a.status = p->status; a.stamps = p->stamps;
     p->epoch += 5u * (unsigned)s.layers;
-    const double wbytes = 2.0 * ((double)s.layers * ((double)s.qkv() * s.H + (double)s.H * s.H + 3.0 * s.I * s.H) + (double)s.NS * s.H);
+    const double wbytes = (p->w_head_lo ? 4.0 : 2.0) * ((double)s.layers * ((double)s.qkv() * s.H + (double)s.H * s.H + 3.0 * s.I * s.H) + (double)s.NS * s.H);
     ProfScope prof("llm_decode32", wbytes, stream);
-    std::lock_guard<std::mutex> lk(g32_mu);
-    if (!g32_ev) HIP_TRY(hipEventCreateWithFlags(&g32_ev, hipEventDisableTiming));
-    else HIP_TRY(hipStreamWaitEvent(stream, g32_ev, 0));
+    PersistentChain& chain = persistent_chain();
+    std::lock_guard<std::mutex> lk(chain.mu);
+    if (!chain.ev) HIP_TRY(hipEventCreateWithFlags(&chain.ev, hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(stream, chain.ev, 0));
+    if (p->w_head_lo) {
+        if (p->kind == 7 && p->TG == 8) hipLaunchKernelGGL((llm_decode32_k<7, 8, true>), dim3(p->G), dim3(512), D32_LDS, stream, a);
+        else if (p->kind == 7) hipLaunchKernelGGL((llm_decode32_k<7, 4, true>), dim3(p->G), dim3(512), D32_LDS, stream, a);
+        else if (p->TG == 8) hipLaunchKernelGGL((llm_decode32_k<2, 8, true>), dim3(p->G), dim3(512), D32_LDS, stream, a);
+        else hipLaunchKernelGGL((llm_decode32_k<2, 4, true>), dim3(p->G), dim3(512), D32_LDS, stream, a);
+    } else
     if (p->kind == 7 && p->TG == 8) hipLaunchKernelGGL((llm_decode32_k<7, 8>), dim3(p->G), dim3(512), D32_LDS, stream, a);
     else if (p->kind == 7) hipLaunchKernelGGL((llm_decode32_k<7, 4>), dim3(p->G), dim3(512), D32_LDS, stream, a);
     else if (p->TG == 8) hipLaunchKernelGGL((llm_decode32_k<2, 8>), dim3(p->G), dim3(512), D32_LDS, stream, a);
     else hipLaunchKernelGGL((llm_decode32_k<2, 4>), dim3(p->G), dim3(512), D32_LDS, stream, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(g32_ev, stream));
+    HIP_TRY(hipEventRecord(chain.ev, stream));
     return FY_OK;
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "../../include/fy_cosy3.h"
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -36,6 +37,18 @@ struct DevPool {
         for (void* p : ptrs) (void)hipFree(p);
     }
 };
+
+// Two persistent grids (llm_decode_k: 152 workgroups, llm_decode32_k: 76) that are each only partly resident would wait for each
+// other's CUs until the spin bound, so the launches of ALL handles of a device - of both kernels - are chained through ONE event:
+// a launch waits on the GPU for the previous persistent launch.  Usage: lock mu; wait ev if set (else create); launch; record ev.
+struct PersistentChain {
+    std::mutex mu;
+    hipEvent_t ev = nullptr;
+};
+PersistentChain& persistent_chain();        // of the calling thread's current device
+// the calling thread's current device ordinal, clamped to [0, FY_MAX_DEVICES): the key of per-device one-time state
+#define FY_MAX_DEVICES 64
+int current_device_slot();
 
 // n host ints -> device memory WITHOUT a copy engine or a stream synchronisation: the values ride in the kernel arguments of tiny
 // launches (256 per launch), so the host buffer may die at once and the caller's stream never waits for the host - a call

@@ -291,3 +291,14 @@ int upload_ints(int* dst, const int* src, int n, hipStream_t st) {
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
+
+int current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev < FY_MAX_DEVICES ? dev : FY_MAX_DEVICES - 1;
+}
+
+PersistentChain& persistent_chain() {
+    static PersistentChain chains[FY_MAX_DEVICES];
+    return chains[current_device_slot()];
+}

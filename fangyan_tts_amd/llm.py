@@ -13,20 +13,24 @@ from ._lib import check
 from .spec import LlmCfg
 
 
-def _cfg_struct(cfg: LlmCfg) -> _lib.LlmConfig:
+def _cfg_struct(cfg: LlmCfg, weight_planes: int = 0) -> _lib.LlmConfig:
     c = _lib.LlmConfig()
     _lib.lib().fy_llm_default_config(C.byref(c))
     c.hidden, c.layers, c.q_heads, c.kv_heads, c.head_dim = cfg.hidden, cfg.layers, cfg.q_heads, cfg.kv_heads, cfg.head_dim
     c.inter, c.vocab, c.speech_tokens, c.rms_eps, c.rope_theta = cfg.inter, cfg.vocab, cfg.speech_tokens, cfg.rms_eps, cfg.rope_theta
+    c.weight_planes = weight_planes
     return c
 
 
 class LlmEngine:
-    """weights: the llm.pt state_dict (reference key names, fp32 CUDA tensors; lm_head not needed)."""
+    """weights: the llm.pt state_dict (reference key names, fp32 CUDA tensors; lm_head not needed).
+    weight_planes: 0 (default) = the library chooses - two bf16 planes per matrix (w = hi + lo) exactly when some weight is not
+    bf16-representable, as in a real checkpoint (the reference runs llm.pt in fp32, cli/cosyvoice.py:193), else one; 1 / 2 force it."""
 
     def __init__(self, weights: Dict[str, torch.Tensor], cfg: LlmCfg = LlmCfg(), max_batch: int = 8, max_ctx: int = 1024,
-                 device: Optional[torch.device] = None, keep_weights: bool = False):
+                 device: Optional[torch.device] = None, keep_weights: bool = False, weight_planes: int = 0):
         self.cfg = cfg
+        self._weight_planes = weight_planes
         self.device = device or next(iter(weights.values())).device
         self.max_batch, self.max_ctx = max_batch, max_ctx
         self._h = C.c_void_p()
@@ -37,7 +41,7 @@ class LlmEngine:
 
     def _create(self, weights):
         arr, keep = _lib.tensor_table(weights)
-        cs = _cfg_struct(self.cfg)
+        cs = _cfg_struct(self.cfg, self._weight_planes)
         with torch.cuda.device(self.device):
             check(_lib.lib().fy_llm_create(C.byref(self._h), C.byref(cs), arr, len(weights), self.max_batch, self.max_ctx, self._stream()))
         del keep
@@ -151,14 +155,24 @@ class LlmEngine:
         self._uniforms = u                                   # borrowed by the library until the next call
         check(_lib.lib().fy_llm_set_sampler(self._h, 1, u.data_ptr(), u.shape[1], top_k, top_p, win_size, tau_r))
 
-    def set_decode_mode(self, persistent: bool):
-        """True (default): one persistent launch per token step (lowest latency; holds most of the chip while it runs).
-        False: one launch per operation, whose short kernels interleave with other streams (what tts_pipeline uses)."""
-        check(_lib.lib().fy_llm_set_decode_mode(self._h, 1 if persistent else 0))
+    def set_decode_mode(self, persistent):
+        """True / 1 (default): one persistent launch per token step (lowest latency; for <= 8 sequences it holds most of the chip).
+        False / 0: one launch per operation, whose short kernels interleave with other streams.
+        2: only the few-CU persistent step (any batch <= 32) - what tts_pipeline uses beside its flow decoders."""
+        check(_lib.lib().fy_llm_set_decode_mode(self._h, int(persistent)))
 
     @property
     def persistent(self) -> bool:
         return bool(_lib.lib().fy_llm_decode_mode(self._h))
+
+    @property
+    def decode_mode(self) -> int:
+        """0, 1 or 2 as set_decode_mode takes them (0 also when the handle has no persistent step for the mode asked for)."""
+        return int(_lib.lib().fy_llm_decode_mode(self._h))
+
+    @property
+    def weight_planes(self) -> int:
+        return int(_lib.lib().fy_llm_weight_planes(self._h))
 
     def logp(self, step: int, B: int) -> torch.Tensor:
         buf = torch.empty(B, self.cfg.n_speech, device=self.device)

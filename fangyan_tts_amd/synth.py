@@ -10,9 +10,12 @@ weights").  Each element is a pure function of (tensor name, flat index), so
 * any prefix / row subset of a huge tensor (SineGen2's 7.2 M x 9 noise table,
   the 151 936-row text embedding) can be produced without the rest.
 
-Matrix-shaped weights are rounded to bf16-representable fp32 values: the engine
-stores them as bf16 without loss, so engine-vs-oracle differences measure the
-kernels, not a quantisation step.
+Matrix-shaped weights are by default rounded to bf16-representable fp32 values: the
+engine stores them as bf16 without loss, so engine-vs-oracle differences measure the
+kernels, not a quantisation step.  A real checkpoint (`llm.pt` is an fp32 state dict,
+cli/model.py:65-73) is NOT bf16-representable: `unrounded_weights()` switches the
+rounding off (and gives weight-norm g a general scale), which is what the `*_fp32w`
+fixtures and the engine's exact-weights mode are held to.
 """
 from __future__ import annotations
 
@@ -25,6 +28,31 @@ _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 _GOLD = np.uint64(0x9E3779B97F4A7C15)
 _C1 = np.uint64(0xBF58476D1CE4E5B9)
 _C2 = np.uint64(0x94D049BB133111EB)
+
+_ROUND_BF16 = True          # matrix-shaped weights are rounded to bf16-representable values (see unrounded_weights)
+
+
+def weight_rounding() -> bool:
+    return _ROUND_BF16
+
+
+def set_weight_rounding(on: bool) -> bool:
+    """Switch the bf16 rounding of matrix-shaped weights; returns the previous setting."""
+    global _ROUND_BF16
+    prev, _ROUND_BF16 = _ROUND_BF16, bool(on)
+    return prev
+
+
+class unrounded_weights:
+    """`with synth.unrounded_weights():` - general fp32 weights, as a real checkpoint holds them."""
+
+    def __enter__(self):
+        self.prev = set_weight_rounding(False)
+        return self
+
+    def __exit__(self, *exc):
+        set_weight_rounding(self.prev)
+        return False
 
 
 def name_seed(name: str) -> int:
@@ -145,9 +173,10 @@ def _gen(name, kind, arg, shape, full_shape, start):
         fan_in = int(np.prod(full_shape[1:])) if len(full_shape) > 1 else full_shape[0]
         a = float(arg) * np.sqrt(3.0 / fan_in)
         x = uniform(name, shape, -a, a, start)
-        return bf16_round(x) if kind == "w" else x
+        return bf16_round(x) if kind == "w" and _ROUND_BF16 else x
     if kind == "emb":
-        return bf16_round(uniform(name, shape, -arg, arg, start))
+        x = uniform(name, shape, -arg, arg, start)
+        return bf16_round(x) if _ROUND_BF16 else x
     if kind == "b":
         return uniform(name, shape, -arg, arg, start)
     if kind == "one":
@@ -171,6 +200,8 @@ def weight_norm_g(v: np.ndarray) -> np.ndarray:
     co = v.shape[0]
     nrm = np.sqrt((v.astype(np.float64).reshape(co, -1) ** 2).sum(axis=1))
     s = np.where(np.arange(co) % 3 == 0, 0.5, 1.0)
+    if not _ROUND_BF16:
+        s = s * (0.8 + 0.4 * ((np.arange(co) * 7) % 11) / 10.0)        # a general scale: the fold is not a power of two
     return (nrm * s).astype(np.float32).reshape(co, 1, 1)
 
 
@@ -266,9 +297,9 @@ def _tensor_device(name: str, shape, device):
     if kind in ("w", "wf32"):
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
         a = float(arg) * np.sqrt(3.0 / fan_in)
-        lo, hi, flags = -a, a, (1 if kind == "w" else 0)
+        lo, hi, flags = -a, a, (1 if kind == "w" and _ROUND_BF16 else 0)
     elif kind == "emb":
-        lo, hi, flags = -arg, arg, 1
+        lo, hi, flags = -arg, arg, (1 if _ROUND_BF16 else 0)
     elif kind == "b":
         lo, hi, flags = -arg, arg, 0
     elif kind == "one":
@@ -301,9 +332,9 @@ def tensor_torch(name: str, shape, device="cpu"):
         fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
         a = float(arg) * np.sqrt(3.0 / fan_in)
         x = uni(-a, a)
-        return _bf16_round_torch(x).reshape(shape) if kind == "w" else x
+        return _bf16_round_torch(x).reshape(shape) if kind == "w" and _ROUND_BF16 else x
     if kind == "emb":
-        return _bf16_round_torch(uni(-arg, arg)).reshape(shape)
+        return _bf16_round_torch(uni(-arg, arg)).reshape(shape) if _ROUND_BF16 else uni(-arg, arg)
     if kind == "b":
         return uni(-arg, arg)
     if kind == "one":
@@ -346,6 +377,8 @@ def state_dict_torch(manifest, device="cpu", skip: Iterable[str] = ()):
             co = v.shape[0]
             nrm = torch.sqrt((v.to(torch.float64).reshape(co, -1) ** 2).sum(dim=1))
             s = torch.where(torch.arange(co, device=v.device) % 3 == 0, 0.5, 1.0).to(torch.float64)
+            if not _ROUND_BF16:
+                s = s * (0.8 + 0.4 * ((torch.arange(co, device=v.device) * 7) % 11).to(torch.float64) / 10.0)
             out[name] = (nrm * s).to(torch.float32).reshape(co, 1, 1)
     if "llm.model.lm_head.weight" in out and "llm.model.model.embed_tokens.weight" in out:
         out["llm.model.lm_head.weight"] = out["llm.model.model.embed_tokens.weight"]

@@ -164,6 +164,11 @@ typedef struct fy_llm fy_llm;
 typedef struct fy_llm_config {           /* Qwen2-0.5B body + CosyVoice3LM heads, llm/llm.py:641-668 */
     int32_t hidden, layers, q_heads, kv_heads, head_dim, inter, vocab, speech_tokens;
     float rms_eps, rope_theta;
+    /* How the matrices are stored (the reference keeps llm.pt in fp32, cli/cosyvoice.py:193 fp16=False, cli/model.py:65-73):
+     * 1 = one bf16 plane - exact only for bf16-representable weights; 2 = two bf16 planes w = hi + lo (values kept to 2^-17
+     * relative, text embedding in fp32: token ids track the fp32 reference on a general checkpoint; twice the weight bytes per
+     * token step, no 8-row persistent step); 0 = choose: 2 exactly when some matrix element is not bf16-representable.      */
+    int32_t weight_planes;
 } fy_llm_config;
 
 void fy_llm_default_config(fy_llm_config* cfg);
@@ -217,9 +222,14 @@ int fy_llm_set_sampler(fy_llm* l, int32_t kind, const float* uniforms, int64_t n
  * but its workgroups hold 152 CUs while they wait on each other, so concurrent streams (a flow decoder beside it, other LM
  * handles) get the rest of the chip only; two such launches never overlap.  mode 0: one launch per operation (121 per step)
  * - slower alone, but its short kernels interleave with other streams' work.  Token ids are identical in both modes.
+ * mode 2: only the FEW-CU persistent step (one launch per token step on 76 workgroups, for any batch <= 32 - what a pipeline that
+ * runs flow decoders beside the LM wants: a call of <= 8 sequences then never takes the 152-workgroup step, whose grid would wait
+ * for residency beside them); larger batches or handles without that step run one launch per operation.
  * fy_llm_decode_mode returns the mode in effect (0 when the persistent kernel is not available for this handle).        */
 int fy_llm_set_decode_mode(fy_llm* l, int32_t mode);
 int fy_llm_decode_mode(const fy_llm* l);
+/* 1 or 2: how this handle stores its matrices (fy_llm_config.weight_planes resolved at create).                      */
+int fy_llm_weight_planes(const fy_llm* l);
 /* log_softmax of step `step` (0 = first generated token) of the last fy_llm_generate call, (B, speech_tokens+200).
  * Only the first FY_LLM_KEEP_LOGP steps are kept.                                                            */
 #define FY_LLM_KEEP_LOGP 4

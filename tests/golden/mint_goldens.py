@@ -493,12 +493,32 @@ def main():
     ap.add_argument("--only", default="hift,flow,llm,e2e,stream,ras")
     ap.add_argument("--full", action="store_true", help="also mint the full-size (CosyVoice3-0.5B shape) fixtures")
     ap.add_argument("--sized", action="store_true", help="mint the fixtures at BASELINE.json's configuration sizes (*_sized.npz; minutes of CPU)")
+    ap.add_argument("--fp32-weights", action="store_true",
+                    help="mint the *_fp32w.npz fixtures: the same cases with synth's bf16 rounding of the matrices switched OFF - "
+                         "general fp32 weights, as a real llm.pt / flow.pt / hift.pt holds them (cli/model.py:65-73)")
     ap.add_argument("--out", default=HERE)
     a = ap.parse_args()
     torch.manual_seed(0)
     install_stubs()
     only = set(a.only.split(","))
     tiny = ModelCfg.tiny()
+    if a.fp32_weights:
+        # every other fixture feeds the reference weights that happen to be bf16-exact, so the one quantisation
+        # step a real checkpoint goes through in a bf16-storage engine is outside them.  These are the reference on unrounded weights.
+        with synth.unrounded_weights():
+            if "llm" in only:
+                mint_llm("tiny_fp32w", tiny.llm, [(12, 8, 0), (10, 6, 30)], a.out, max_steps=400)
+                mint_llm("full_fp32w", LlmCfg(), [(12, 8, 0), (14, 10, 40)], a.out, max_steps=60)
+            if "flow" in only:
+                mint_flow("tiny_fp32w", tiny.flow, [16, 150], [(20, 10)], a.out)
+                mint_flow("full_fp32w", FlowCfg(), [16, 150], [(20, 0)], a.out)
+            if "hift" in only:
+                mint_hift("tiny_fp32w", tiny.hift, [30], a.out)
+                mint_hift("full_fp32w", HiftCfg(), [30], a.out)
+            if "e2e" in only:
+                mint_e2e("tiny_fp32w", tiny, [(8, 6, 0, 12)], a.out)
+                mint_e2e("sized_fp32w", ModelCfg(), [(14, 8, 0, 125)], a.out)
+        return
     if a.sized:
         # SURVEY 8(c) G3 / G5 / G6 at the sizes BASELINE.json's configurations run at: the DiT at T = 512 (the top of
         # export_onnx.py's sweep) and T = 650 (config 3: 10 s prompt + 3 s), the 10-step mel at config 2's (75 tokens, 5 s
