@@ -442,7 +442,7 @@ def main():
     def deliver(wav, samples, toks):
         """The metric's end point: all wavs resident on the host - after the all-gather for N > 1."""
         if world > 1:
-            wav, _ = gather_audio(wav.cpu() if rehearsal else wav, samples, b_max=BATCH, s_max=S_MAX)
+            wav, _ = gather_audio(wav.cpu() if rehearsal else wav, samples, b_max=BATCH, s_max=S_MAX, reuse=not rehearsal)   # the GPU path copies the result to the host at once
         last["wav"], last["toks"], last["mel"] = wav.cpu(), toks, model.last_mel       # D2H inside the timed region
         return samples
 
@@ -658,6 +658,65 @@ def main():
             precise["pipelined"] = {"ms_per_step": round(pp_ms, 2), "audio_s_per_s": round(audio_per_step / (pp_ms * 1e-3), 2), "steps": a.steps,
                                     "note": "the timed run of the headline repeated with the flow decoder in FY_PRECISE"}
 
+    # ---- the price of a GENERAL fp32 checkpoint in the LM (llm.pt is fp32, cli/model.py:65-73; the reference runs it as saved): every
+    # matrix as two bf16 planes w = hi + lo - the mode fy_llm_create picks by itself when a weight is not bf16-representable, and in
+    # which the ids equal the reference's on unrounded weights (tests/test_fp32w_gpu.py).  Same workload and pipeline as the headline,
+    # a second model whose LM is FORCED to two planes on the same weights (their lo planes are zero: same ids, the cost of the mode).
+    exact_w = None
+    if rank == 0 and world == 1 and not a.no_extras:
+        log("the same workload with the LM in its exact-weights mode (two bf16 planes per matrix)")
+        model2 = CosyVoice3Model(sd_llm, sd_flow, sd_hift, cfg, device=dev, max_batch=BATCH, max_text=64, max_prompt_tokens=P_TOK,
+                                 max_tokens=N_TOK, rand_noise=noise, rand_ini=ri, sine_noise=sn, n_llm=n_llm, lm_group=group,
+                                 flow_workers=a.flow_workers if pipelined else 1, flow_group=a.flow_group if pipelined else 1, llm_weight_planes=2)
+        try:
+            assert all(e.weight_planes == 2 for e in model2.llms)
+            step2 = lambda: model2.tts_batch(inputs, min_len=forced, max_len=forced, keep_on_device=True)
+
+            def run2(k):
+                r = None
+                for r in model2.tts_pipeline([inputs] * k, min_len=[forced] * k, max_len=[forced] * k, keep_on_device=True):
+                    r[0].cpu()
+                return r
+            wav2, _, toks2 = step2()
+            torch.cuda.synchronize()
+            ids_equal = all(torch.equal(x.cpu(), y.cpu()) for x, y in zip(toks2, model.tts_batch(inputs, min_len=forced, max_len=forced, keep_on_device=True)[2]))
+            t6 = time.perf_counter()
+            for _ in range(3):
+                step2()[0].cpu()
+            torch.cuda.synchronize()
+            xw_ms = 1e3 * (time.perf_counter() - t6) / 3
+            xw_pipe = None
+            if pipelined:
+                model2.prepare_pipeline(a.flow_cu_exclude)
+                run2(a.warmup or 4)
+                torch.cuda.synchronize()
+                t7 = time.perf_counter()
+                run2(a.steps)
+                torch.cuda.synchronize()
+                xw_pipe = 1e3 * (time.perf_counter() - t7) / a.steps
+            e2 = model2.llms[0]
+            e2.set_decode_mode(2)
+            gen2 = lambda: e2.generate(text * G, ptext * G, [[] for _ in range(BATCH * G)], min_len=forced * G, max_len=forced * G)
+            gen2()
+            torch.cuda.synchronize()
+            t8 = time.perf_counter()
+            gen2()
+            torch.cuda.synchronize()
+            xw_gen = 1e3 * (time.perf_counter() - t8)
+            exact_w = {"what": "the headline's workload with the LM storing every matrix as two bf16 planes (w = hi + lo: a general fp32 llm.pt keeps its "
+                               "values to 2^-17 relative; ids equal the reference's on unrounded weights, tests/test_fp32w_gpu.py); 1.456 GB of weights per token step",
+                       "ms_per_step_pipelined": round(xw_pipe, 3) if xw_pipe else None,
+                       "audio_s_per_s_pipelined": round(audio_per_step / (xw_pipe * 1e-3), 2) if xw_pipe else None,
+                       "ms_per_step_unpipelined": round(xw_ms, 2), "audio_s_per_s_unpipelined": round(audio_per_step / (xw_ms * 1e-3), 2),
+                       "one_plane_ms_per_step": {"pipelined": round(1e3 * dt / a.steps, 3), "unpipelined": round(latency_ms, 2)},
+                       "lm_call_alone_ms": {"rows": BATCH * G, "tokens": N_TOK, "ms": round(xw_gen, 2), "ms_per_token_step": round(xw_gen / N_TOK, 4),
+                                            "weight_GBps_at_token_step_level": round(2 * step_bytes / (xw_gen / N_TOK * 1e-3) / 1e9, 1)},
+                       "ids_equal_one_plane_run": bool(ids_equal), "steps": a.steps}
+        finally:
+            model2.close()
+            del model2
+            torch.cuda.empty_cache()
+
     out = {
         "metric": "synthesised audio sec/sec (RTF^-1) CosyVoice3-0.5B instruct, batch 8",
         "value": round(value, 3), "unit": "audio_s/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -682,6 +741,7 @@ def main():
         "roofline_lm": roofline_lm,
         "roofline_lm_persistent": roofline_lm_p,
         "precise_mode": precise,
+        "exact_weights": exact_w,
     }
     if rank == 0 and world == 1 and not a.no_extras:
         # behind the timed region: BASELINE.json configs[0], configs[2] and configs[4] as secondary objects of the same record

@@ -130,6 +130,8 @@ def _declare(L):
     L.fy_llm_set_decode_mode.argtypes = [vp, i32]
     L.fy_llm_decode_mode.argtypes = [vp]
     L.fy_llm_weight_planes.argtypes = [vp]
+    L.fy_set_host_wait.argtypes = [i32, i32]
+    L.fy_flow_weight_planes.argtypes = [vp]
     L.fy_debug_decode_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
     L.fy_debug_decode32_stamps.argtypes = [vp, C.POINTER(C.c_uint64), i32, vp]
     L.fy_debug_gemm_exact.argtypes = [vp, vp, i32, i32, i32, vp, vp, i32, vp, vp]
@@ -152,6 +154,27 @@ def tensor_table(weights):
         for k, s in enumerate(t.shape):
             arr[i].shape[k] = s
     return arr, keep
+
+
+HOST_WAIT_SLEEP_S = 2e-4          # stream_wait's poll interval; fy_set_host_wait gets the same figure
+
+
+def host_wait_spin() -> bool:
+    return os.environ.get("FY_HOST_WAIT_SPIN", "0") == "1"
+
+
+def stream_wait(stream):
+    """Wait for everything enqueued on a torch stream WITHOUT spinning on a core: an event polled with short sleeps (what
+    `stream.synchronize()` costs under HIP's default schedule is a whole core per waiting thread; a pipelined rank has 3-4)."""
+    if host_wait_spin():
+        stream.synchronize()
+        return
+    import time
+    import torch
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    while not ev.query():
+        time.sleep(HOST_WAIT_SLEEP_S)
 
 
 def int_array(values):

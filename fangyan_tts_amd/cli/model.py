@@ -33,7 +33,7 @@ class CosyVoice3Model:
                  rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
                  sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False, n_llm: int = 1,
                  sampler: str = "greedy", sampler_seed: int = 1986, lm_group: int = 1, concurrency: int = 1, flow_workers: int = 1,
-                 flow_group: int = 1, cache_prompts: bool = True, incremental_stream: bool = True):
+                 flow_group: int = 1, cache_prompts: bool = True, incremental_stream: bool = True, llm_weight_planes: int = 0):
         if not torch.cuda.is_available():
             raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -56,8 +56,11 @@ class CosyVoice3Model:
         # lm_group > 1: tts_pipeline decodes that many consecutive batches in ONE LM call (the weights stream once per
         # decode step for all of them and the launch count per batch drops), then runs flow + vocoder batch by batch
         self.lm_group = max(1, lm_group)
+        # llm_weight_planes: how the LM stores its matrices (llm.py: LlmEngine) - 0 = two bf16 planes (w = hi + lo, ids track the fp32
+        # reference on a general checkpoint) exactly when llm.pt is not bf16-representable, else one; 1 / 2 force it
         self.llms = [LlmEngine(llm_weights, cfg.llm, max_batch=max_batch * self.lm_group, max_ctx=2 + max_text + max_prompt_tokens + max_tokens,
-                               device=self.device, keep_weights=keep_llm_weights and i == 0) for i in range(max(1, n_llm))]
+                               device=self.device, keep_weights=keep_llm_weights and i == 0, weight_planes=llm_weight_planes)
+                     for i in range(max(1, n_llm))]
         self.llm = self.llms[0]
         # LM handles decoding beside the flow decoder (tts_pipeline) use the one-launch-per-operation decode: its short
         # kernels interleave with the other streams, while the persistent step holds 152 CUs for its whole duration
@@ -80,7 +83,8 @@ class CosyVoice3Model:
         self.lanes = [_Lane(self.llm, self.flow, self.hift, None)]
         for _ in range(1, max(1, concurrency)):
             self.lanes.append(_Lane(
-                LlmEngine(llm_weights, cfg.llm, max_batch=max_batch, max_ctx=2 + max_text + max_prompt_tokens + max_tokens, device=self.device),
+                LlmEngine(llm_weights, cfg.llm, max_batch=max_batch, max_ctx=2 + max_text + max_prompt_tokens + max_tokens, device=self.device,
+                          weight_planes=llm_weight_planes),
                 FlowEngine(flow_weights, cfg.flow, max_batch=max_batch, max_frames=max_frames, device=self.device),
                 HiftEngine(hift_weights, cfg.hift, max_batch=max_batch, max_frames=2 * max_tokens, device=self.device),
                 torch.cuda.Stream(device=self.device)))
@@ -166,6 +170,7 @@ class CosyVoice3Model:
     def _lane_stream(self, ln):
         """The lane's stream as the current stream for the engine calls inside (lanes after the first have their own)."""
         import contextlib
+        from .. import _lib as _l0s
 
         @contextlib.contextmanager
         def cm():
@@ -175,7 +180,7 @@ class CosyVoice3Model:
                 ln.stream.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(ln.stream):
                     yield
-                ln.stream.synchronize()
+                _l0s.stream_wait(ln.stream)
         return cm()
 
     def _take_lane(self):
@@ -273,6 +278,7 @@ class CosyVoice3Model:
         import sys
         import threading as th
         import time
+        from .. import _lib as _lib_w
         trace = bool(os.environ.get("FY_PIPE_TRACE"))        # per-stage wall times on stderr
         dev = self.device
         n_prod = len(self.llms)
@@ -318,7 +324,8 @@ class CosyVoice3Model:
                         self._arm_sampler(pi, [box["base"] + bi for bi in group], [len(batches[bi]) for bi in group])
                         t0 = time.perf_counter()
                         out, out_n, _ = llm.generate(text, ptext, pspeech, min_len=mn, max_len=mx)
-                        n_tok = out_n.cpu().tolist()              # synchronises the LM stream: the ids are complete
+                        _lib_w.stream_wait(lm_stream)             # the ids are complete (polled with sleeps: no core spins on the LM stream)
+                        n_tok = out_n.cpu().tolist()
                         if trace:
                             print(f"[pipe] LM handle {pi} batches {group}: {1e3 * (time.perf_counter() - t0):.1f} ms", file=sys.stderr)
                         o = 0
@@ -391,7 +398,7 @@ class CosyVoice3Model:
                             if keep_on_device:
                                 res, ev = wav, torch.cuda.Event()
                                 ev.record(st)
-                                st.synchronize()
+                                _lib_w.stream_wait(st)
                             else:
                                 res, ev = wav.cpu(), None
                         if trace:
@@ -420,6 +427,12 @@ class CosyVoice3Model:
             p32 = bool(int(_os.environ.get("FY_PIPE_LM_PERSISTENT32", "1")))
             for e in self.llms:
                 e.set_decode_mode(2 if p32 else 0)
+            # For the pipeline's duration the host threads that wait for the device - the LM producers (inside fy_llm_step and for
+            # their ids), the flow workers - poll with sleeps instead of spinning (fy_set_host_wait, _lib.stream_wait): they wait
+            # most of the time, and spinning they cost 2.7 cores per rank = 22 on an 8-rank host (measured 138 -> 52 ms of
+            # process CPU per 50 ms step at the same step time).  tts / tts_batch keep hipStreamSynchronize: one thread, and a
+            # 75-token generation looks at its stop flags ten times (+4 ms with 200 us sleeps).  FY_HOST_WAIT_SPIN=1: spin here too.
+            _lib_w.check(_lib_w.lib().fy_set_host_wait(0 if _lib_w.host_wait_spin() else 1, int(_lib_w.HOST_WAIT_SLEEP_S * 1e6)))
             box["base"] = self._next_batch_ids(len(batches))
             for t in threads:
                 t.start()
@@ -460,6 +473,7 @@ class CosyVoice3Model:
                         t.join(timeout=0.05)
                 for e, p in zip(self.llms, was_persistent):
                     e.set_decode_mode(p)
+                _lib_w.lib().fy_set_host_wait(0, int(_lib_w.HOST_WAIT_SLEEP_S * 1e6))
 
     def prepare_pipeline(self, flow_cu_exclude: Optional[int] = None):
         """Place the pipeline's streams now (otherwise the first tts_pipeline call does it, ~0.1-0.4 s)."""

@@ -7,6 +7,7 @@
 //                     (query row, query head); serves prefill rows and decode steps alike
 //                     (transformers Qwen2Attention as called from llm/llm.py:246-258).
 #include "attn.h"
+#include "runtime.h"
 #include "gemv32.h"
 #include <algorithm>
 #include <stdlib.h>
@@ -413,9 +414,13 @@ template <int W>
 static int dit_attention_split_launch(const bf16_t* qh, const bf16_t* ql, bf16_t* oh, bf16_t* ol, const int* seq_len, int nseq, int Tmax, int H, int chunk,
                                       dim3 grid, hipStream_t st) {
     constexpr size_t lds = (size_t)2 * (2 * 64 * AT_KP + 2 * 64 * AT_VP) * sizeof(bf16_t);      // 86 016 B: above the 64 KB default
-    // set once per process and kernel (a thread-safe function-local static: several flow handles may make their first call at once)
-    static const hipError_t attr = hipFuncSetAttribute((const void*)dit_attention_split_k<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    HIP_TRY(attr);
+    // set once per device and kernel (several flow handles may make their first call at once: the setup is idempotent)
+    static PerDeviceOnce attr_once;
+    const int dslot = current_device_slot();
+    if (!attr_once.done[dslot].load(std::memory_order_acquire)) {
+        HIP_TRY(hipFuncSetAttribute((const void*)dit_attention_split_k<W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_once.done[dslot].store(true, std::memory_order_release);
+    }
     hipLaunchKernelGGL((dit_attention_split_k<W>), grid, dim3(W * 64), lds, st, qh, ql, oh, ol, seq_len, Tmax, H, chunk, 0.125f * 1.4426950408889634f);
     HIP_TRY(hipGetLastError());
     return FY_OK;

@@ -758,10 +758,11 @@ static int launch_resblock_iter(const ResIterDesc& d, const ConvW& w1, const Con
     const size_t lds = std::max((size_t)(TP + h1) * ROWB, (size_t)TP * ROWB + (size_t)WP * WC * 32 * 68 * sizeof(float));
     FY_CHECK(lds <= 160 * 1024, FY_ERR_ARG, "conv_resblock_iter: needs %zu B of LDS", lds);
     auto kern = resblock_iter_k<WP, WC, INB>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;                                  // per device, not per process
+    const int dslot = current_device_slot();
+    if (!attr_once.done[dslot].load(std::memory_order_acquire)) {
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+        attr_once.done[dslot].store(true, std::memory_order_release);
     }
     ProfScope prof("conv_mfma", 2.0 * 2.0 * d.B * d.L * (double)C * C * d.KW, st);
     dim3 grid(cdiv(d.L, P2), 1, d.B);

@@ -16,6 +16,9 @@
 struct FlowBlockW {
     bf16_t *wqkv, *wo, *w1, *w2, *wmod;
     float *bqkv, *bo, *b1, *b2, *bmod;
+    // lo planes bf16(w - bf16(w)), same layouts, kept only when some weight of flow.pt is not bf16-representable (fy_flow::planes == 2):
+    // FY_PRECISE then multiplies by w = hi + lo (gemm_split's w_lo), and the create-time modulation vectors use both planes
+    bf16_t *wqkv_lo = nullptr, *wo_lo = nullptr, *w1_lo = nullptr, *w2_lo = nullptr, *wmod_lo = nullptr;
 };
 
 struct fy_flow {
@@ -27,6 +30,9 @@ struct fy_flow {
     ConvW pre1, pre2, pos1, pos2;
     // estimator
     bf16_t *w_in, *w_out, *w_t0, *w_t2, *w_fin;
+    bf16_t *w_in_lo = nullptr, *w_out_lo = nullptr, *w_t0_lo = nullptr, *w_t2_lo = nullptr, *w_fin_lo = nullptr;
+    int planes = 1;            // 2: a general fp32 checkpoint (cli/model.py:65-73) - the lo planes above are kept
+    float* ones = nullptr;     // [dim] ones (the gate of a lo-plane pass that adds into an fp32 output)
     float *b_in, *b_out, *b_t0, *b_t2, *b_fin;
     std::vector<FlowBlockW> blk;
     float* mod = nullptr;      // [(n_steps+1)][depth][6*dim]   (slot n_steps = scratch for fy_dit_estimator)
@@ -223,6 +229,31 @@ static int copy_f32(fy_flow* f, const float* src, size_t n, float** dst, hipStre
     return FY_OK;
 }
 
+__global__ void flow_bf16_residual_k(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = blockIdx.x * 256UL + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i] - bf16_to_f32(f32_to_bf16(src[i]));
+}
+__global__ void flow_bf16_inexact_k(const float* __restrict__ src, size_t n, unsigned long long* __restrict__ count) {
+    unsigned long long c = 0;
+    for (size_t i = blockIdx.x * 256UL + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) c += bf16_to_f32(f32_to_bf16(src[i])) != src[i];
+    if (c) atomicAdd(count, c);
+}
+__global__ void flow_fill_k(float* p, float v, int n) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+static unsigned flow_grid(size_t n) { return (unsigned)std::min<size_t>(4096, (n + 255) / 256); }
+// the lo plane of src [N][K], row-major (packed = false) or in the GEMV's fragment order; f->planes == 1: nothing
+static int lo_plane(fy_flow* f, const float* src, int N, int K, bool packed, bf16_t** dst, hipStream_t st) {
+    if (f->planes != 2) return FY_OK;
+    float* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)N * K * sizeof(float)));
+    hipLaunchKernelGGL(flow_bf16_residual_k, dim3(flow_grid((size_t)N * K)), dim3(256), 0, st, src, tmp, (size_t)N * K);
+    int rc = packed ? to_packed(f, tmp, N, K, dst, st) : to_bf16(f, tmp, (size_t)N * K, dst, st);
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    return rc;
+}
+
 // modulation vectors of one set of timesteps: slot0.. (rows = n), see modules.py:606-616, 239-241, 260-261
 static int compute_mod(fy_flow* f, const float* t_host, int n, int slot0, hipStream_t st) {
     const fy_flow_config& c = f->cfg;
@@ -242,21 +273,28 @@ static int compute_mod(fy_flow* f, const float* t_host, int n, int slot0, hipStr
     HIP_TRY(hipStreamSynchronize(st));
     GemvArgs a;
     a.W = f->w_t0; a.x = d_emb; a.ldx = 256; a.R = n; a.N = D; a.K = 256; a.bias = f->b_t0; a.y = f->tsil; a.ldy = D;
-    FY_TRY(gemv_bf16w(a, st));
+    // a product with both weight planes (general fp32 weights): y = W x + b, then y += W_lo x
+    auto both = [&](GemvArgs g, const bf16_t* w_lo) -> int {
+        FY_TRY(gemv_bf16w(g, st));
+        if (!w_lo) return FY_OK;
+        g.W = w_lo; g.bias = nullptr; g.mode = GV_ADD;
+        return gemv_bf16w(g, st);
+    };
+    FY_TRY(both(a, f->w_t0_lo));
     hipLaunchKernelGGL(silu_k, dim3(cdiv(n * D, 256)), dim3(256), 0, st, f->tsil, f->tsil, (long)n * D);
     a.W = f->w_t2; a.x = f->tsil; a.ldx = D; a.K = D; a.bias = f->b_t2; a.y = f->temb;
-    FY_TRY(gemv_bf16w(a, st));
+    FY_TRY(both(a, f->w_t2_lo));
     hipLaunchKernelGGL(silu_k, dim3(cdiv(n * D, 256)), dim3(256), 0, st, f->temb, f->tsil, (long)n * D);
     for (int i = 0; i < c.depth; ++i) {
         GemvArgs m;
         m.W = f->blk[i].wmod; m.x = f->tsil; m.ldx = D; m.R = n; m.N = 6 * D; m.K = D; m.bias = f->blk[i].bmod;
         m.y = f->mod + ((size_t)slot0 * c.depth + i) * 6 * D; m.ldy = c.depth * 6 * D;
-        FY_TRY(gemv_bf16w(m, st));
+        FY_TRY(both(m, f->blk[i].wmod_lo));
     }
     GemvArgs m;
     m.W = f->w_fin; m.x = f->tsil; m.ldx = D; m.R = n; m.N = 2 * D; m.K = D; m.bias = f->b_fin;
     m.y = f->fin + (size_t)slot0 * 2 * D; m.ldy = 2 * D;
-    FY_TRY(gemv_bf16w(m, st));
+    FY_TRY(both(m, f->w_fin_lo));
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -299,6 +337,29 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
     }
     const std::string E = "decoder.estimator.";
     {
+        // does one bf16 plane per matrix lose anything?  (every estimator tensor with two or more dimensions: the linears and the
+        // position convolutions; synthetic parity weights: no - a real flow.pt: yes, and FY_PRECISE then needs the lo planes)
+        unsigned long long* cnt = nullptr;
+        TRYC(f->pool.alloc(&cnt, (size_t)2));
+        if (hipMemsetAsync(cnt, 0, 16, st) != hipSuccess) { fy_set_error("fy_flow_create: memset failed"); return fail(FY_ERR_HIP); }
+        for (int i = 0; i < n_weights; ++i) {
+            const fy_tensor& t = weights[i];
+            if (!t.name || !t.data || t.ndim < 2 || strncmp(t.name, E.c_str(), E.size()) != 0) continue;
+            size_t n = 1;
+            for (int d = 0; d < t.ndim; ++d) n *= (size_t)t.shape[d];
+            hipLaunchKernelGGL(flow_bf16_inexact_k, dim3(flow_grid(n)), dim3(256), 0, st, (const float*)t.data, n, cnt);
+        }
+        unsigned long long n_inexact = 0;
+        if (hipMemcpyAsync(&n_inexact, cnt, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            fy_set_error("fy_flow_create: weight scan failed");
+            return fail(FY_ERR_HIP);
+        }
+        f->planes = n_inexact ? 2 : 1;
+        if (const char* e = getenv("FY_FLOW_WEIGHT_PLANES")) { if (atoi(e) == 1 || atoi(e) == 2) f->planes = atoi(e); }
+        TRYC(f->pool.alloc(&f->ones, (size_t)D));
+        hipLaunchKernelGGL(flow_fill_k, dim3(cdiv(D, 256)), dim3(256), 0, st, f->ones, 1.0f, D);
+    }
+    {
         GETW(t0w, E + "time_embed.time_mlp.0.weight", D, 256);
         GETW(t0b, E + "time_embed.time_mlp.0.bias", D);
         GETW(t2w, E + "time_embed.time_mlp.2.weight", D, D);
@@ -314,6 +375,9 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
         TRYC(to_bf16(f, iw, (size_t)D * 4 * C, &f->w_in, st)); TRYC(copy_f32(f, ib, D, &f->b_in, st));
         TRYC(to_bf16(f, ow, (size_t)C * D, &f->w_out, st)); TRYC(copy_f32(f, ob, C, &f->b_out, st));
         TRYC(to_packed(f, fw, 2 * D, D, &f->w_fin, st)); TRYC(copy_f32(f, fb, 2 * D, &f->b_fin, st));
+        TRYC(lo_plane(f, t0w, D, 256, true, &f->w_t0_lo, st)); TRYC(lo_plane(f, t2w, D, D, true, &f->w_t2_lo, st));
+        TRYC(lo_plane(f, iw, D, 4 * C, false, &f->w_in_lo, st)); TRYC(lo_plane(f, ow, C, D, false, &f->w_out_lo, st));
+        TRYC(lo_plane(f, fw, 2 * D, D, true, &f->w_fin_lo, st));
         const int cg = D / c.conv_pos_groups;
         GETW(c1w, E + "input_embed.conv_pos_embed.conv1.0.weight", D, cg, c.conv_pos_k);
         GETW(c1b, E + "input_embed.conv_pos_embed.conv1.0.bias", D);
@@ -350,6 +414,23 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
         TRYC(to_bf16(f, ow, (size_t)D * inner, &k.wo, st)); TRYC(copy_f32(f, ob, D, &k.bo, st));
         TRYC(to_bf16(f, f1w, (size_t)FF * D, &k.w1, st)); TRYC(copy_f32(f, f1b, FF, &k.b1, st));
         TRYC(to_bf16(f, f2w, (size_t)D * FF, &k.w2, st)); TRYC(copy_f32(f, f2b, D, &k.b2, st));
+        if (f->planes == 2) {
+            TRYC(lo_plane(f, mw, 6 * D, D, true, &k.wmod_lo, st));
+            TRYC(f->pool.alloc(&k.wqkv_lo, (size_t)3 * inner * D));
+            float* tmp = nullptr;
+            if (hipMalloc(&tmp, (size_t)inner * D * sizeof(float)) != hipSuccess) { fy_set_error("fy_flow_create: out of memory"); return fail(FY_ERR_HIP); }
+            int rc3 = FY_OK;
+            for (int j = 0; j < 3 && rc3 == FY_OK; ++j) {
+                hipLaunchKernelGGL(flow_bf16_residual_k, dim3(flow_grid((size_t)inner * D)), dim3(256), 0, st, ws[j], tmp, (size_t)inner * D);
+                rc3 = cast_f32_bf16(tmp, k.wqkv_lo + (size_t)j * inner * D, (size_t)inner * D, st);
+            }
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(tmp);
+            TRYC(rc3);
+            TRYC(lo_plane(f, ow, D, inner, false, &k.wo_lo, st));
+            TRYC(lo_plane(f, f1w, FF, D, false, &k.w1_lo, st));
+            TRYC(lo_plane(f, f2w, D, FF, false, &k.w2_lo, st));
+        }
     }
     // activations
     const size_t B = max_batch, T = f->Tmax, N = f->Nmax, M = 2 * B * T;
@@ -398,6 +479,8 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
 
 extern "C" void fy_flow_destroy(fy_flow* f) { delete f; }
 
+extern "C" int fy_flow_weight_planes(const fy_flow* f) { return f ? f->planes : 0; }
+
 // lo planes of the fp32-class mode, sized for the handle's capacity, on first use
 static int ensure_precise(fy_flow* f) {
     const fy_flow_config& c = f->cfg;
@@ -425,7 +508,7 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
     const bool pr = (flags & FY_PRECISE) != 0;
     GemmEpi e;
     e.bias = f->b_in; e.out = f->h; e.out_bf16 = 0; e.ldc = D;
-    if (pr) { e.a_lo = f->a_in_lo; FY_TRY(gemm_split(f->a_in, 4 * C, f->w_in, M, D, 4 * C, e, st)); }
+    if (pr) { e.a_lo = f->a_in_lo; e.w_lo = f->w_in_lo; e.gate_ones = f->ones; FY_TRY(gemm_split(f->a_in, 4 * C, f->w_in, M, D, 4 * C, e, st)); }
     else FY_TRY(gemm_bf16(f->a_in, 4 * C, f->w_in, M, D, 4 * C, e, st));
     {   // x = conv_pos_embed(x) + x, modules.py:129-144 (causal, grouped, Mish)
         ConvDesc d;
@@ -434,7 +517,8 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
         d.x = f->h; d.x_bs = (long)Tmax * D; d.x_ld = D; d.L_in = Tmax; d.in_len = f->seq_len;
         d.y = f->c1; d.y_bs = (long)Tmax * D; d.y_ld = D; d.L_out = Tmax; d.out_len = f->seq_len;
         d.Cin = D; d.Cout = D; d.KW = c.conv_pos_k; d.pad_left = c.conv_pos_k - 1; d.bias = f->pos1.bias; d.post_act = ACT_MISH;
-        const bool mf = f->pos1.w_mfma != nullptr && !(flags & FY_DIRECT);
+        // (FY_PRECISE on weights that are not bf16-representable: the exact fp32 kernel, which keeps the fp32 weights)
+        const bool mf = f->pos1.w_mfma != nullptr && !(flags & FY_DIRECT) && !(pr && f->planes == 2);
         FY_TRY(mf ? conv1d_bf16_mfma(d, f->pos1, (flags & FY_PRECISE) != 0, st) : conv1d_f32_direct(d, f->pos1, st));
         d.x = f->c1; d.y = f->h; d.bias = f->pos2.bias;
         d.add_resid = 1; d.resid = f->h; d.r_bs = (long)Tmax * D; d.r_ld = D;
@@ -452,7 +536,7 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
         // sums before they are rounded to bf16 (or split into the two planes)
         q.rope = f->rope; q.rope_T = Tmax; q.rope_half = c.head_dim / 2; q.rope_stride = inner;
         if (pr) {
-            q.a_lo = f->xn_lo; q.out_lo = f->qkv_lo;
+            q.a_lo = f->xn_lo; q.out_lo = f->qkv_lo; q.w_lo = k.wqkv_lo;
             FY_TRY(gemm_split(f->xn, D, k.wqkv, M, 3 * inner, D, q, st));
             FY_TRY(dit_attention_split(f->qkv, f->qkv_lo, f->ao, f->ao_lo, f->seq_len, nseq, Tmax, c.heads, streaming ? c.static_chunk : 0, st));
         } else {
@@ -461,23 +545,23 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
         }
         GemmEpi o;
         o.mode = EPI_GATE_RESID; o.bias = k.bo; o.resid = f->h; o.gate = m + 2 * D; o.ldc = D;
-        if (pr) { o.a_lo = f->ao_lo; FY_TRY(gemm_split(f->ao, inner, k.wo, M, D, inner, o, st)); }
+        if (pr) { o.a_lo = f->ao_lo; o.w_lo = k.wo_lo; o.gate_ones = f->ones; FY_TRY(gemm_split(f->ao, inner, k.wo, M, D, inner, o, st)); }
         else FY_TRY(gemm_bf16(f->ao, inner, k.wo, M, D, inner, o, st));
         hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + 4 * D, m + 3 * D, f->xn, xn_lo, M, D);
         GemmEpi g;
         g.bias = k.b1; g.act = ACT_GELU_TANH; g.out = f->ff; g.out_bf16 = 1; g.ldc = FF;
-        if (pr) { g.a_lo = f->xn_lo; g.out_lo = f->ff_lo; FY_TRY(gemm_split(f->xn, D, k.w1, M, FF, D, g, st)); }
+        if (pr) { g.a_lo = f->xn_lo; g.out_lo = f->ff_lo; g.w_lo = k.w1_lo; FY_TRY(gemm_split(f->xn, D, k.w1, M, FF, D, g, st)); }
         else FY_TRY(gemm_bf16(f->xn, D, k.w1, M, FF, D, g, st));
         GemmEpi r;
         r.mode = EPI_GATE_RESID; r.bias = k.b2; r.resid = f->h; r.gate = m + 5 * D; r.ldc = D;
-        if (pr) { r.a_lo = f->ff_lo; FY_TRY(gemm_split(f->ff, FF, k.w2, M, D, FF, r, st)); }
+        if (pr) { r.a_lo = f->ff_lo; r.w_lo = k.w2_lo; r.gate_ones = f->ones; FY_TRY(gemm_split(f->ff, FF, k.w2, M, D, FF, r, st)); }
         else FY_TRY(gemm_bf16(f->ff, FF, k.w2, M, D, FF, r, st));
     }
     const float* fn = f->fin + (size_t)slot * 2 * D;            // (scale, shift), modules.py:261
     hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, fn, fn + D, f->xn, xn_lo, M, D);
     GemmEpi p;
     p.bias = f->b_out; p.out = f->v; p.out_bf16 = 0; p.ldc = C;
-    if (pr) { p.a_lo = f->xn_lo; FY_TRY(gemm_split(f->xn, D, f->w_out, M, C, D, p, st)); }
+    if (pr) { p.a_lo = f->xn_lo; p.w_lo = f->w_out_lo; p.gate_ones = f->ones; FY_TRY(gemm_split(f->xn, D, f->w_out, M, C, D, p, st)); }
     else FY_TRY(gemm_bf16(f->xn, D, f->w_out, M, C, D, p, st));
     HIP_TRY(hipGetLastError());
     return FY_OK;

@@ -30,6 +30,10 @@ struct GemmEpi {
     // out_lo = lo plane, both bf16 [M][ldc]) for the next product, after the exact-tanh GELU (act) or the rotary embedding (rope)
     const bf16_t* a_lo = nullptr;
     const bf16_t* a_lo2 = nullptr;     // the third plane of an EXACT three-way split x = hi + mid (a_lo) + lo (a_lo2): gemm_exact3
+    // gemm_split only: the lo plane of the WEIGHTS, W_true = W + w_lo with W = bf16(w), w_lo = bf16(w - W), [N][K] like W (general
+    // fp32 checkpoints; null = the weights are bf16-representable).  The K loop then runs a second pass over w_lo.
+    const bf16_t* w_lo = nullptr;
+    const float* gate_ones = nullptr;  // N ones: needed with w_lo only where gemm_split falls back to the register-staged kernel (N % 128 != 0)
     void* out_lo = nullptr;
 #ifdef FY_GEMM_STAMPS
     int stamp_slot = 0;                // tests/micro/gemm_stamps.hip: which 4096-workgroup slot of the stamp buffer this launch writes
@@ -47,7 +51,8 @@ int gemm_f32a_precise(const float* A, int lda, const bf16_t* W, int M, int N, in
 
 // A = A_hi + epi.a_lo, two bf16 planes [M][lda] written by the producer (16 mantissa bits): two MFMAs per fragment into one fp32
 // accumulator on the LDS-DMA ring kernel - the fp32-class (FY_PRECISE) flow decoder at 2x the MFMA work of gemm_bf16, not the
-// register-staged fp32 path's 5x.  Outputs: fp32 store, gated residual, or split bf16 planes (epi.out_lo).
+// register-staged fp32 path's 5x.  Outputs: fp32 store, gated residual, or split bf16 planes (epi.out_lo).  With epi.w_lo the
+// weights are two planes as well (4x the MFMA work).
 int gemm_split(const bf16_t* A_hi, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st);
 
 // A: fp32 [M][lda], split EXACTLY into bf16 hi + mid + lo (3 MFMAs per fragment): with bf16-exact W every product is exact and

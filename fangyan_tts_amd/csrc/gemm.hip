@@ -2,6 +2,7 @@
 #include "gemm.h"
 #include "runtime.h"
 #include <algorithm>
+#include <atomic>
 #include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 frag_ab;
@@ -302,6 +303,14 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
     G2_STAMP(0);
 
+    // K steps: K / 32 - or, for the split-operand form with a second weight plane (e.w_lo), twice that: steps [ntk, 2 ntk) walk
+    // the same A columns again against the lo plane of W (same rows, same pitch: one pointer difference)
+    const int ntk = K / G2_BK;
+    const bool w2 = SP == 1 && e.w_lo != nullptr;
+    const int nt = w2 ? 2 * ntk : ntk;
+    const long wdelta = w2 ? (long)(e.w_lo - W) : 0L;
+    auto kofs = [&](int t) -> int { if constexpr (SP == 1) return (t >= ntk ? t - ntk : t) * G2_BK; else return t * G2_BK; };
+    auto wofs = [&](int t) -> long { if constexpr (SP == 1) return t >= ntk ? wdelta : 0L; else return 0L; };
     // wave-instruction j fills stage bytes [j * 1024, +1024) of the A (and B) tile:
     // row = j*16 + lane/4, slot = lane%4  ->  logical chunk = slot ^ ((row >> 2) & 3)
     const bf16_t* a_src[NA];
@@ -326,19 +335,19 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
         char* st = smem + (t % STAGES) * STAGE;
         if (d < NA) {
             if (d + 1 < NA || a_last)
-                __builtin_amdgcn_global_load_lds((const void*)(a_src[d] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + (d * NWAVE + wid) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void*)(a_src[d] + kofs(t)), (__attribute__((address_space(3))) void*)(st + (d * NWAVE + wid) * 1024), 16, 0, 0);
         } else
-            __builtin_amdgcn_global_load_lds((const void*)(b_src[d - NA] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + BOFF + wid * NB * 1024 + (d - NA) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(b_src[d - NA] + wofs(t) + kofs(t)), (__attribute__((address_space(3))) void*)(st + BOFF + wid * NB * 1024 + (d - NA) * 1024), 16, 0, 0);
     };
     auto issue = [&](int t) {
         char* st = smem + (t % STAGES) * STAGE;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
             if (i + 1 < NA || a_last)
-                __builtin_amdgcn_global_load_lds((const void*)(a_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + (i * NWAVE + wid) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void*)(a_src[i] + kofs(t)), (__attribute__((address_space(3))) void*)(st + (i * NWAVE + wid) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_global_load_lds((const void*)(b_src[i] + t * G2_BK), (__attribute__((address_space(3))) void*)(st + BOFF + wid * NB * 1024 + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void*)(b_src[i] + wofs(t) + kofs(t)), (__attribute__((address_space(3))) void*)(st + BOFF + wid * NB * 1024 + i * 1024), 16, 0, 0);
     };
 
     f32x16 acc[MI][2];
@@ -372,7 +381,6 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
             for (int j = 0; j < 4; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    const int nt = K / G2_BK;
 #pragma unroll
     for (int t = 0; t < STAGES - 1; ++t)
         if (t < nt) issue(t);
@@ -755,11 +763,12 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
 
 template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0, int SP = 0>
 static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set[FY_MAX_DEVICES];       // per device: the attribute belongs to the device's copy of the function
     const size_t lds = (size_t)3 * ((SP + 1) * BM + BN) * G2_BK * 2;          // 256x256: 96 KB; 320x256: 108 KB (one workgroup per CU); 256x128: 72 KB (two); 128x128: 48 KB (three); split operand: 256x128 120 KB (one), 128x128 72 KB (two)
-    if (!attr_set) {
+    const int dev_slot = current_device_slot();
+    if (!attr_set[dev_slot].load(std::memory_order_acquire)) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN, BM, STAG, MF, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev_slot].store(true, std::memory_order_release);
     }
     dim3 grid((N / BN) * cdiv(M, BM));
     hipLaunchKernelGGL((gemm256_k<EPI, BN, BM, STAG, MF, SP>), grid, dim3(BM == 128 ? 256 : 512), lds, st, A, lda, W, M, N, K, epi);
@@ -769,11 +778,12 @@ static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int
 
 template <int PRECISE, int EPI, int BM>
 static int gemm_launch3(const void* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set[FY_MAX_DEVICES];
     const size_t lds = (size_t)2 * ((PRECISE == 4 ? 2 : (PRECISE ? PRECISE : 1)) * BM + GM_BN) * GM_PITCH * sizeof(bf16_t);
-    if (!attr_set) {
+    const int dev_slot = current_device_slot();
+    if (!attr_set[dev_slot].load(std::memory_order_acquire)) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_k<PRECISE, EPI, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
+        attr_set[dev_slot].store(true, std::memory_order_release);
     }
     dim3 grid(cdiv(N, GM_BN) * cdiv(M, BM));
     hipLaunchKernelGGL((gemm_bf16_k<PRECISE, EPI, BM>), grid, dim3(BM * 2), lds, st, A, lda, W, M, N, K, epi);
@@ -873,14 +883,25 @@ static int gemm_split_launch(const bf16_t* A, int lda, const bf16_t* W, int M, i
         if (tile == 256) return gemm_launch_256<EPI, 128, 256, 0, 1, 1>(A, lda, W, M, N, K, epi, st);
         return gemm_launch_256<EPI, 128, 128, 0, 1, 1>(A, lda, W, M, N, K, epi, st);
     }
-    if constexpr (EPI == 2 || EPI == 3) return gemm_launch3<4, EPI, 128>(A, lda, W, M, N, K, epi, st);
+    if constexpr (EPI == 2 || EPI == 3) {
+        // the register-staged kernel knows one weight plane: the lo plane is a second launch that adds into the first one's output
+        // (both epilogues are linear in the product), through the gated residual form - epi.gate_ones: a vector of N ones
+        FY_TRY((gemm_launch3<4, EPI, 128>(A, lda, W, M, N, K, epi, st)));
+        if (!epi.w_lo) return FY_OK;
+        FY_CHECK(epi.gate_ones, FY_ERR_ARG, "gemm_split: a second weight plane on the register-staged kernel needs epi.gate_ones");
+        GemmEpi e2;
+        e2.mode = EPI_GATE_RESID; e2.gate = epi.gate_ones; e2.ldc = epi.ldc; e2.a_lo = epi.a_lo;
+        e2.resid = EPI == 3 ? epi.resid : (float*)epi.out;
+        return gemm_launch3<4, 3, 128>(A, lda, epi.w_lo, M, N, K, e2, st);
+    }
     FY_CHECK(false, FY_ERR_ARG, "gemm_split: a split-plane output needs N %% 128 == 0 and K %% 32 == 0 (N %d, K %d)", N, K);
 }
 
 int gemm_split(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     FY_TRY(gemm_check(A, lda, W, M, N, K, epi, 2));
     FY_CHECK(epi.a_lo && ((uintptr_t)epi.a_lo & 15) == 0, FY_ERR_ARG, "gemm_split: the lo plane of A is missing or misaligned");
-    ProfScope prof("gemm_split", 4.0 * M * N * K, st);
+    FY_CHECK(!epi.w_lo || ((uintptr_t)epi.w_lo & 15) == 0, FY_ERR_ARG, "gemm_split: the lo plane of W is misaligned");
+    ProfScope prof("gemm_split", (epi.w_lo ? 8.0 : 4.0) * M * N * K, st);
     if (epi.mode == EPI_GATE_RESID) return gemm_split_launch<3>(A, lda, W, M, N, K, epi, st);
     if (epi.out_lo) {
         FY_CHECK(epi.act == ACT_NONE || (epi.act == ACT_GELU_TANH && !epi.rope), FY_ERR_ARG, "gemm_split: only GELU(tanh) or the rotary embedding is fused");
@@ -1261,11 +1282,12 @@ int gemv_bf16w(const GemvArgs& a, hipStream_t st) {
     } else {
         FY_CHECK(a.K <= GV_SLICE && a.K % 128 == 0 && a.ldx % 4 == 0 && ((uintptr_t)a.x & 15) == 0, FY_ERR_ARG,
                  "gemv: the LDS-staged form needs K <= %d, K %% 128 == 0 (K = %d)", GV_SLICE, a.K);
-        static bool attr_set = false;
+        static PerDeviceOnce attr_once;
+        const int dslot = current_device_slot();
         const size_t lds = (size_t)24 * GV_PITCH * 2 + 4 * 256 * 4 + 8 * 4;
-        if (!attr_set) {
+        if (!attr_once.done[dslot].load(std::memory_order_acquire)) {
             HIP_TRY(hipFuncSetAttribute((const void*)gemv_lds_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
+            attr_once.done[dslot].store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL(gemv_lds_k, grid, dim3(256), lds, st, a);
     }

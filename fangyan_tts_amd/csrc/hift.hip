@@ -382,9 +382,11 @@ __global__ void istft16_k(const float* __restrict__ spec, float* __restrict__ wa
     wav[(long)b * Fmax * up + n] = fminf(fmaxf(y, -limit), limit);
 }
 
-static bool g_tables_ready = false;
+// __constant__ tables are per device: filled once per device (idempotent, so two handles' first calls may both do it)
+static PerDeviceOnce g_tables_once;
 static int init_tables() {
-    if (g_tables_ready) return FY_OK;
+    const int dslot = current_device_slot();
+    if (g_tables_once.done[dslot].load(std::memory_order_acquire)) return FY_OK;
     float c[16], s[16], w[16];
     for (int i = 0; i < 16; ++i) {
         c[i] = (float)cos(2.0 * M_PI * i / 16.0);
@@ -394,7 +396,7 @@ static int init_tables() {
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_cos16), c, sizeof(c)));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_sin16), s, sizeof(s)));
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(c_hann16), w, sizeof(w)));
-    g_tables_ready = true;
+    g_tables_once.done[dslot].store(true, std::memory_order_release);
     return FY_OK;
 }
 

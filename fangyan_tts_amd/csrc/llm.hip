@@ -917,7 +917,7 @@ static int llm_begin_rows(fy_llm* l, const int* n_rows, const int32_t* min_len, 
     HIP_TRY(hipMemcpyAsync(l->row_pos, rpos.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(l->last_row, last.data(), mb * sizeof(int), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(l->st, stv.data(), stv.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(stream_wait(st));
     l->B = B;
     if (l->gv32 && !llm_prefill_by_gemm(l, R)) FY_TRY(gv32_split_rows(l->h, H, R, H, l->L[0].ln1, l->img_h, l->ssq, st));
     FY_TRY(llm_layers(l, R, l->row_seq, l->row_pos, false, st));
@@ -967,7 +967,7 @@ extern "C" int fy_llm_begin(fy_llm* l, const int32_t* text_ids, const int32_t* n
     const int R = (int)src.size();
     FY_CHECK(R <= l->max_rows, FY_ERR_ARG, "fy_llm_generate: %d prefill rows exceed the workspace (%d)", R, l->max_rows);
     HIP_TRY(hipMemcpyAsync(l->row_src, src.data(), R * sizeof(int), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));                        // src dies with this frame
+    HIP_TRY(stream_wait(st));                        // src dies with this frame
     hipLaunchKernelGGL(embed_rows_k, dim3(R), dim3(256), 0, st, l->row_src, l->embed_tokens, l->embed_tokens_f32, l->speech_emb, l->h, H);
     return llm_begin_rows(l, rows.data(), min_len, max_len, B, out_ids, out_ld, st);
 }
@@ -1018,7 +1018,7 @@ extern "C" int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t
         // and the handle then works on the per-operation path (fy_llm_set_decode_mode(0)) as the message says
         if (persistent) FY_TRY(decode_status(l->dec, &dec_status, st));
         if (persistent32) FY_TRY(decode32_status(l->dec32, &dec_status, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(stream_wait(st));
         if (dec_status != 0) {
             l->step_next = 0;                // the generation is void: no further steps are launched on it
             FY_CHECK(false, FY_ERR_STATE, "fy_llm_step: the decode kernel's grid hand-off timed out (its workgroups were not all resident: "
@@ -1059,7 +1059,7 @@ extern "C" int fy_llm_step(fy_llm* l, int32_t n_steps, int32_t* out_ids, int32_t
     if (l->sampler == 1) {                   // the reference raises RuntimeError from sampling_ids (llm.py:161-162)
         std::vector<int> used(mb);
         HIP_TRY(hipMemcpyAsync(used.data(), l->st + 7 * mb, mb * sizeof(int), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(stream_wait(st));
         for (int b = 0; b < B; ++b) {
             FY_CHECK(done[b] != 2, FY_ERR_STATE, "sampling reaches max_trials 100 and still get eos when ignore_eos is True (sequence %d)", b);
             FY_CHECK(used[b] <= l->n_uniforms, FY_ERR_ARG, "fy_llm_generate: sequence %d needed %d uniforms, %ld were supplied", b, used[b], l->n_uniforms);

@@ -49,6 +49,15 @@ PersistentChain& persistent_chain();        // of the calling thread's current d
 // the calling thread's current device ordinal, clamped to [0, FY_MAX_DEVICES): the key of per-device one-time state
 #define FY_MAX_DEVICES 64
 int current_device_slot();
+// One-time setup that belongs to a DEVICE (a function attribute, __constant__ tables): `static PerDeviceOnce once;`, tested and set at
+// done[current_device_slot()] with acquire / release - safe from several threads (two threads may both do the setup: it is idempotent).
+#include <atomic>
+struct PerDeviceOnce {
+    std::atomic<bool> done[FY_MAX_DEVICES];
+};
+
+// hipStreamSynchronize, or - after fy_set_host_wait(1, us) - hipStreamQuery polled with sleeps in between (runtime.hip)
+hipError_t stream_wait(hipStream_t st);
 
 // n host ints -> device memory WITHOUT a copy engine or a stream synchronisation: the values ride in the kernel arguments of tiny
 // launches (256 per launch), so the host buffer may die at once and the caller's stream never waits for the host - a call

@@ -302,3 +302,28 @@ PersistentChain& persistent_chain() {
     static PersistentChain chains[FY_MAX_DEVICES];
     return chains[current_device_slot()];
 }
+
+// How the library's host threads wait for a stream in its hot paths (fy_llm_step's look at the stop flags every 8 token steps, the
+// prefill's uploads).  hipStreamSynchronize spins on a core under HIP's default schedule - and on this stack (ROCm 7.0 runtime under
+// torch 2.10) hipDeviceScheduleBlockingSync changes nothing about that (tests/micro/blocking_sync_probe.py: 1.0 core either way,
+// and the process then hangs at exit).  A pipelined rank has an LM thread, flow workers and a consumer waiting most of the time:
+// 2.7 cores per rank.  mode 1: poll hipStreamQuery and sleep `sleep_us` between polls - a waiting thread costs ~nothing and a wait
+// ends at most sleep_us late.  Process-wide.
+#include <atomic>
+#include <unistd.h>
+static std::atomic<int> g_wait_mode{0}, g_wait_sleep_us{200};
+extern "C" int fy_set_host_wait(int32_t mode, int32_t sleep_us) {
+    FY_CHECK((mode == 0 || mode == 1) && sleep_us >= 1 && sleep_us <= 100000, FY_ERR_ARG, "fy_set_host_wait: mode 0 (spin) or 1 (poll + sleep), 1 <= sleep_us <= 100000");
+    g_wait_mode.store(mode);
+    g_wait_sleep_us.store(sleep_us);
+    return FY_OK;
+}
+hipError_t stream_wait(hipStream_t st) {
+    if (g_wait_mode.load(std::memory_order_relaxed) == 0) return hipStreamSynchronize(st);
+    const int us = g_wait_sleep_us.load(std::memory_order_relaxed);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        usleep(us);
+    }
+}

@@ -98,6 +98,11 @@ class FlowEngine:
                                        flags, self._stream()))
         return mel
 
+    @property
+    def weight_planes(self) -> int:
+        """1: the weights were bf16-representable; 2: a general fp32 checkpoint (lo planes kept for FY_PRECISE)."""
+        return int(_lib.lib().fy_flow_weight_planes(self._h))
+
     def stream_reset(self):
         """Forget what incremental calls have kept: the next one starts a new stream."""
         check(_lib.lib().fy_flow_stream_reset(self._h))

@@ -34,15 +34,17 @@ def plan_shards(costs: Sequence[float], world: int, batch: Optional[int] = None)
     monotone in the LM's step count).  Returns plan[rank] = that rank's batches, each a list of utterance indices.
 
     * utterances are sorted by cost, longest first (ties keep the input order), and the sorted order is cut into batches of
-      `batch` (default: ceil(n / world), one batch per rank): the members of a batch have neighbouring lengths, so the
-      steps a batch decodes for its longest member are wasted on few rows;
+      `batch`: the members of a batch have neighbouring lengths, so the steps a batch decodes for its longest member are
+      wasted on few rows.  Default: ceil(n / world) rounded DOWN to batches of at most 8 (the engines' batch) with at least two
+      batches per rank when there are that many utterances - one contiguous block of the sorted order per rank would hand
+      rank 0 all the longest utterances (flow and vocoder work follow the SUM of lengths) and could balance nothing;
     * a batch costs max(cost) * size (what the padded decode runs); batches go, most expensive first, to the rank with the
       least cost so far (ties: the lowest rank) - the longest-processing-time rule, deterministic, computed identically on
       every rank from the same costs with no communication."""
     n = len(costs)
     assert world >= 1
     if batch is None:
-        batch = max(1, -(-n // world))
+        batch = max(1, min(8, -(-n // (2 * world))))
     order = sorted(range(n), key=lambda i: (-float(costs[i]), i))
     batches = [order[o: o + batch] for o in range(0, n, batch)]
     weight = [max(float(costs[i]) for i in b) * len(b) for b in batches]
@@ -84,7 +86,11 @@ class AudioGather:
     b_max rows of s_max samples, then the count and the lengths bit-cast to float behind them.  On the GPU the record is
     packed by the library's kernel with the lengths in its arguments (`fy_audio_record_pack`): no allocation, no host-to-device
     copy and no stream synchronisation per step; the caller's first look at the lengths is the one device-to-host read of
-    the gathered headers."""
+    the gathered headers.
+
+    With one rank the returned audio is a VIEW of this object's preallocated `out` buffer (with more ranks the rows are copied out
+    from between the headers): the next call overwrites it.  A caller that keeps a result across calls clones it (gather_audio
+    does, unless told `reuse=True`)."""
 
     def __init__(self, b_max: int, s_max: int, device, group=None):
         self.b_max, self.s_max, self.group = int(b_max), int(s_max), group
@@ -121,27 +127,53 @@ class AudioGather:
         return out[:, :per].reshape(self.world * self.b_max, self.s_max), per_rank
 
 
-_gathers = {}
+# one AudioGather per (bounds, device, group): keyed by the group OBJECT through a WeakKeyDictionary (an id() can be recycled by a
+# new group after the old one was destroyed; the entry of a destroyed group goes with it), the default group under a plain key
+import weakref
+
+_gathers_by_group: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_gathers_default = {}
+
+
+def _gather_cache(group):
+    if group is None:
+        # the default group can be destroyed and re-created: entries made for an earlier one are dropped
+        cur = dist.distributed_c10d._get_default_group() if dist.is_initialized() else None
+        if _gathers_default.get("group") is not cur:
+            _gathers_default.clear()
+            _gathers_default["group"] = cur
+        return _gathers_default
+    try:
+        return _gathers_by_group.setdefault(group, {})
+    except TypeError:                      # a group object that cannot be weakly referenced: no caching
+        return {}
 
 
 def gather_audio(wav: torch.Tensor, n_samples: Sequence[int], group=None, b_cap: int = 64,
-                 b_max: int = 0, s_max: int = 0) -> Tuple[torch.Tensor, List[List[int]]]:
+                 b_max: int = 0, s_max: int = 0, reuse: bool = False) -> Tuple[torch.Tensor, List[List[int]]]:
     """wav (b, S) of this rank's utterances, n_samples their valid lengths ->
     (all wavs (world * b_max, S_max) in rank order, per-rank length lists) on every rank.
 
     With the bounds known to every rank up front (b_max utterances per rank, s_max samples: what the engines were created
-    for) the exchange is ONE collective on buffers made once per (bounds, device, group) - `AudioGather`.  Without them: one tiny all-gather of
+    for) the exchange is ONE collective on buffers made once per (bounds, device, group) - `AudioGather`; the result is a fresh
+    tensor (a clone of the gather's buffer) unless `reuse=True`, which hands out the buffer itself - valid until the next call with
+    the same bounds (a step loop that consumes each result before the next step).  Without them: one tiny all-gather of
     (b, S, lengths) in a fixed-size record (b <= b_cap), sizes read on the host, then one fused all-gather of the padded audio."""
     world = dist.get_world_size(group)
     dev = wav.device
     b, S = wav.shape
     assert b <= b_cap and len(n_samples) == b, "more utterances per rank than the header record holds"
     if b_max and s_max:
-        key = (b_max, s_max, str(dev), id(group), world)
-        g = _gathers.get(key)
+        cache = _gather_cache(group)
+        key = (b_max, s_max, str(dev), world)
+        g = cache.get(key)
         if g is None:
-            g = _gathers[key] = AudioGather(b_max, s_max, dev, group)
-        return g(wav, n_samples)
+            g = cache[key] = AudioGather(b_max, s_max, dev, group)
+        out, per_rank = g(wav, n_samples)
+        # with more than one rank the rows come out of the record buffer by a copy already (the headers sit between the ranks' audio);
+        # only a result that still shares the buffer's storage (world 1) needs the clone
+        shares = out.untyped_storage().data_ptr() == g.out.untyped_storage().data_ptr()
+        return (out.clone() if shares and not reuse else out), per_rank
     rec = 2 + b_cap
     head = torch.zeros(rec, dtype=torch.int64)
     head[0], head[1] = b, S

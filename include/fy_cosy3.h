@@ -32,6 +32,12 @@ typedef struct fy_tensor {
 
 const char* fy_last_error(void);
 int fy_version(void);
+/* How the library's host threads wait for a stream in its hot paths (fy_llm_step's look at the stop flags every 8 token steps):
+ * mode 0 = hipStreamSynchronize (spins on a core under HIP's default schedule), mode 1 = hipStreamQuery polled with `sleep_us`
+ * microseconds of sleep between polls - a waiting thread costs next to nothing, a wait ends at most sleep_us late.  A pipelined
+ * rank has 3-4 threads that wait most of the time (the host-side cost of one process per GPU); the Python mirror
+ * switches to mode 1 (200 us; FY_HOST_WAIT_SPIN=1 keeps mode 0) and waits for its own streams the same way.  Process-wide.        */
+int fy_set_host_wait(int32_t mode, int32_t sleep_us);
 
 /* ---- opt-in launch profiler: HIP events around the named kernels' launches, on their stream.
  * names: "gemm_bf16" (DiT / projection GEMMs; work = flops), "conv_mfma" (work = flops),
@@ -130,6 +136,11 @@ void fy_flow_default_config(fy_flow_config* cfg);
 int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy_tensor* weights, int32_t n_weights,
                    int32_t max_batch, int32_t max_frames, void* stream);
 void fy_flow_destroy(fy_flow* f);
+/* 1: every estimator matrix of flow.pt was bf16-representable (one bf16 plane each, nothing lost).  2: a general fp32 checkpoint -
+ * the handle also keeps the lo planes bf16(w - bf16(w)); FY_PRECISE multiplies by w = hi + lo (and runs the position convolutions
+ * on the exact fp32 kernel), so it meets the reference's estimator-swap bar (export_onnx.py:109) on such weights too; the default
+ * bf16 mode uses the hi plane only.  The step-dependent modulation vectors computed at create use both planes in either mode.     */
+int fy_flow_weight_planes(const fy_flow* f);
 
 /* token (B, tok_ld) int32, prompt_token (B, ptok_ld) int32, prompt_feat (B, pfeat_rows, 80) fp32,
  * embedding (B, 192) fp32 - device; n_token / n_prompt / n_pfeat - host int32[B];

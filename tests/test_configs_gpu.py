@@ -315,3 +315,59 @@ print("OK")
     # an ERROR from ncclGetUniqueId / ncclCommInitRank is a failure (the child says which); only the time-out above - a box whose
     # bootstrap never completes - skips
     assert "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_audio_record_pack_and_cuda_gather_single_rank(tmp_path):
+    """The DEFAULT multi-GPU delivery path of bench.py on a GPU: AudioGather's CUDA branch - fy_audio_record_pack (lengths in the
+    kernel arguments, a row longer than s_max, fewer rows than b_max, a row pitch that is not the row length) + one
+    all_gather_into_tensor over RCCL - against the CPU branch over gloo bit for bit, on a one-rank group of each kind.  In a child
+    process with a time limit (a bootstrap that never completes skips; an error fails)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import os, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda:0")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+cpu_group = dist.new_group(backend="gloo")
+from fangyan_tts_amd import _lib
+from fangyan_tts_amd.parallel import AudioGather, gather_audio
+b, b_max, s_max, S, pitch = 3, 5, 900, 880, 1216
+g = torch.Generator().manual_seed(3)
+big = torch.rand(b, pitch, generator=g)
+wav_cpu = big[:, :S]                                  # not contiguous: the row pitch is 1216
+wav_gpu = big.to(dev)[:, :S]
+assert wav_gpu.stride(0) == pitch
+lens = [2000, 17, 640]                                # row 0 claims more samples than the record holds: cut to s_max, published as min(n, S?) below
+ga, gc = AudioGather(b_max, s_max, dev), AudioGather(b_max, s_max, "cpu", cpu_group)
+# the record itself: the CPU branch's packing is the definition
+out_c, per_c = gc(wav_cpu, [min(n, S) for n in lens])
+out_g, per_g = ga(wav_gpu, [min(n, S) for n in lens])
+torch.cuda.synchronize()
+assert per_g == per_c == [[880, 17, 640]], (per_g, per_c)
+assert torch.equal(ga.mine.cpu().view(torch.int32), gc.mine.view(torch.int32)), "records differ"
+assert torch.equal(out_g.cpu(), out_c)
+# a length beyond the capacity is clamped in the header and the row is cut (the pack kernel never reads past s_max)
+wide = torch.rand(2, 1000, generator=g)
+o2, p2 = ga(wide.to(dev)[:, :900], [950, 3])      # 950 > s_max (and <= the row pitch, which the entry checks)
+torch.cuda.synchronize()
+assert p2 == [[900, 3]] and torch.equal(o2[0].cpu(), wide[0, :900]) and float(o2[1, 3:].abs().max()) == 0.0 and float(o2[2:].abs().max()) == 0.0
+# gather_audio on the GPU: a fresh tensor unless reuse=True
+a, _ = gather_audio(wav_gpu, [min(n, S) for n in lens], b_max=b_max, s_max=s_max)
+b2, _ = gather_audio(wav_gpu * 2, [min(n, S) for n in lens], b_max=b_max, s_max=s_max, reuse=True)
+torch.cuda.synchronize()
+assert torch.equal(a.cpu(), out_c) and a.data_ptr() != b2.data_ptr()
+dist.destroy_process_group()
+print("OK")
+"""
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([root] + sys.path), NCCL_SOCKET_IFNAME=os.environ.get("NCCL_SOCKET_IFNAME", "lo"),
+               GLOO_SOCKET_IFNAME=os.environ.get("GLOO_SOCKET_IFNAME", "lo"), MASTER_ADDR="127.0.0.1", MASTER_PORT="29533",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    try:
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("making a one-rank RCCL process group did not finish on this box")
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    assert "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

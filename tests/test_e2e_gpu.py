@@ -364,3 +364,37 @@ def test_voice_conversion_branch(tiny):
     ref = [o["tts_speech"] for o in m.tts(**inp, stream=True)]
     assert [c.shape for c in chunks] == [c.shape for c in ref]
     assert all(maxerr(a, b) == 0.0 for a, b in zip(chunks, ref))
+
+
+def test_pipeline_tail_group_never_takes_the_152_workgroup_step():
+    """tts_pipeline puts its LM handles in decode mode 2 - only the few-CU persistent step (llm_decode32.hip), for any batch <= 32:
+    a tail group (or a warm-up) of <= 8 sequences must not take the 8-row persistent step, whose 152 workgroups would wait for
+    residency beside the flow streams (and beside another LM handle's grid).  Counted with the launch profiler: no `llm_decode`
+    launch during a pipeline whose groups are 8, 8 and 1 sequences on two LM handles; results equal tts_batch's."""
+    from fangyan_tts_amd import _lib
+    from fangyan_tts_amd.cli.model import CosyVoice3Model
+    cfg = ModelCfg.tiny()
+    sd = [synth.state_dict_torch(mm.manifest(), DEV, skip=("lm_head",)) for mm in (cfg.llm, cfg.flow, cfg.hift)]
+    kw = dict(device=DEV, max_batch=4, max_text=32, max_prompt_tokens=32, max_tokens=160)
+    a = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, **kw)
+    b = CosyVoice3Model(sd[0], sd[1], sd[2], cfg, lm_group=2, n_llm=2, flow_workers=2, **kw)
+    b.rand_noise, b.rand_ini, b.sine_noise = a.rand_noise, a.rand_ini, a.sine_noise
+    ins = [e2e_input(cfg, *c)[0] for c in CASES]
+    batches = [[ins[0], ins[1], ins[0], ins[1]]] * 4 + [[ins[1]]]
+    ref = [a.tts_batch(x) for x in batches]
+    L = _lib.lib()
+    L.fy_prof_reset()
+    L.fy_prof_enable(1)
+    try:
+        got = list(b.tts_pipeline(batches))
+        torch.cuda.synchronize()
+    finally:
+        L.fy_prof_enable(0)
+    n8 = _lib.prof_get("llm_decode")[2]
+    n32 = _lib.prof_get("llm_decode32")[2]
+    L.fy_prof_reset()
+    assert n8 == 0 and n32 > 0, (n8, n32)
+    for i, ((w, s, t), (w2, s2, t2)) in enumerate(zip(got, ref)):
+        assert s == s2 and all(torch.equal(x, y) for x, y in zip(t, t2)), i
+    assert b.llm.decode_mode == 1                           # and the handle got its own mode back
+    a.close(); b.close()
