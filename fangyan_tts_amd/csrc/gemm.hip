@@ -46,15 +46,26 @@ __device__ __forceinline__ void split8_3(const float4& a, const float4& b, uint4
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+// The rotation of two interleaved pairs, v = (a, b, c, d), t = (cos0, sin0, cos1, sin1): out = t * cos + rotate_half(t) * sin as the
+// reference computes it (x-transformers apply_rotary_pos_emb: two multiplies and an add, each rounded).  Floating-point contraction is
+// OFF here: left to the compiler, one instantiation of an epilogue fused a multiply-add where another did not, and tilings that
+// accumulate K in the same order came out 3-6 bf16 roundings apart in 20 M outputs - big calls and small calls of the estimator must
+// agree bit for bit (tests/test_flow_gpu.py::test_bench_sized_estimator_equals_pairs, the incremental stream's chunks).
+__device__ __forceinline__ void rope_rotate(float4& v, const float4& t) {
+#pragma clang fp contract(off)
+    const float a = v.x, b = v.y, c = v.z, d = v.w;
+    const float ac = a * t.x, bs = b * t.y, bc = b * t.x, as = a * t.y, cc = c * t.z, ds = d * t.w, dc = d * t.z, cs = c * t.w;
+    v.x = ac - bs; v.y = bc + as;
+    v.z = cc - ds; v.w = dc + cs;
+}
+
 // x-transformers apply_rotary_pos_emb on four consecutive output columns starting at n (two interleaved pairs)
 __device__ __forceinline__ void epi_rope(float4& v, const GemmEpi& e, int m, int n) {
     int nn = n >= e.rope_stride ? n - e.rope_stride : n;
     if (n >= 2 * e.rope_stride || nn >= 2 * e.rope_half) return;
     const float2* tab = e.rope + (long)((m / e.rope_div) % e.rope_T) * e.rope_half + (nn >> 1);
     const float2 c0 = tab[0], c1 = tab[1];
-    const float a = v.x, b = v.y, c = v.z, d = v.w;
-    v.x = a * c0.x - b * c0.y; v.y = b * c0.x + a * c0.y;
-    v.z = c * c1.x - d * c1.y; v.w = d * c1.x + c * c1.y;
+    rope_rotate(v, make_float4(c0.x, c0.y, c1.x, c1.y));
 }
 
 // Epilogue shared by the GEMM kernels, through LDS: the accumulator layout (column on the lane, rows in registers)
@@ -267,6 +278,218 @@ void gemm_set_stamps(unsigned long long* p) { hipMemcpyToSymbol(HIP_SYMBOL(gemm_
 #define G2_DIRECT 1
 #endif
 #define G2_RING_BYTES (96 * 1024)                            // BN 256: three 32 KB stages; BN 128: three 24 KB stages = 72 KB, so that two workgroups share a CU
+
+// The ring kernels' epilogue (gemm256_k, gemm64_k): from the accumulators - acc (32x32x16 form) or acc4 (16x16x32 form; DE: the
+// transposed products, a lane holds 16 consecutive columns of one row per 16-row tile) - to memory, with the bias, the rotary
+// embedding, GELU, the gated residual or the split planes.  Called by every wave of the workgroup after the K loop.
+// FM = 16-row tiles per wave (the wave covers FM * 16 rows x 64 columns); AH: the epilogue may fetch residual / table rows a tile ahead
+// (the one-workgroup-per-CU tilings of 8 waves have the registers for it)
+template <int EPI, int BN, int FM, int MF, bool DE, bool AH>
+__device__ __forceinline__ void ring_epilogue(char* smem, f32x16 (&acc)[(FM + 1) / 2][2], f32x4 (&acc4)[MF ? FM : 1][4], const GemmEpi& e, int M, int N,
+                                              int m0, int n0, int wm, int wn, int wid, int lane) {
+    const int tid = threadIdx.x, lr = lane & 31, kh = lane >> 5;
+    (void)tid; (void)lr; (void)kh;
+    constexpr int MI = FM / 2;                                      // 32-row blocks (the LDS epilogue walks them: FM even there)
+    static_assert(DE || FM % 2 == 0, "the LDS epilogue parks 32-row blocks");
+    __syncthreads();                                                // all waves are done with the ring: the epilogue parks tiles in it
+    G2_STAMP(2);
+
+    constexpr bool RE = EPI == 0 || EPI == 4;                       // epilogues that may carry the rotary embedding
+    if constexpr (DE) {
+        // Direct epilogue: for 16-row tile i the lane holds row (lane & 15), columns nq .. nq + 15 as acc4[i][j][r] = column 4 j + r.
+        // The residual rows (EPI 3) or the rotary table rows (RE) of tile i + 1 are fetched before tile i is stored.
+        const int nq = n0 + wn * 64 + (lane >> 4) * 16, mw = m0 + wm * (FM * 16) + (lane & 15);
+        float4 bq[4], gq[EPI == 3 ? 4 : 1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            bq[c] = e.bias ? *reinterpret_cast<const float4*>(e.bias + nq + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (EPI == 3) gq[c] = *reinterpret_cast<const float4*>(e.gate + nq + 4 * c);
+        }
+        int rope_c = -1;                                            // float2 index of the lane's first pair inside a table row
+        if (RE && e.rope) {
+            const int nn = nq >= e.rope_stride ? nq - e.rope_stride : nq;
+            if (nq < 2 * e.rope_stride && nn < 2 * e.rope_half) rope_c = nn >> 1;
+        }
+        constexpr bool PF = EPI == 3 || RE, AHEAD = AH;      // the one-per-CU tiles have the registers to fetch a tile ahead, and nobody else to hide the trip
+        float4 cur[PF ? 4 : 1], nxt[PF && AHEAD ? 4 : 1];
+        auto fetch = [&](int i, auto& t) {
+            const int m = min(mw + i * 16, M - 1);
+            if constexpr (EPI == 3) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) t[c] = *reinterpret_cast<const float4*>(e.resid + (long)m * e.ldc + nq + 4 * c);
+            } else if constexpr (RE) {
+                if (rope_c >= 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t[c] = *reinterpret_cast<const float4*>(e.rope + (long)((m / e.rope_div) % e.rope_T) * e.rope_half + rope_c + 2 * c);
+                }
+            }
+        };
+        if constexpr (PF && AHEAD) fetch(0, cur);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            if constexpr (PF && AHEAD) { if (i + 1 < FM) fetch(i + 1, nxt); }
+            if constexpr (PF && !AHEAD) fetch(i, cur);
+            const int m = mw + i * 16;
+            if (m < M) {
+                uint32_t pk[8], pl[8];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float4 v = make_float4(acc4[i][c][0], acc4[i][c][1], acc4[i][c][2], acc4[i][c][3]);
+                    v.x += bq[c].x; v.y += bq[c].y; v.z += bq[c].z; v.w += bq[c].w;
+                    if constexpr (EPI == 3) {
+                        float4 o = cur[c];
+                        o.x = fmaf(gq[c].x, v.x, o.x); o.y = fmaf(gq[c].y, v.y, o.y); o.z = fmaf(gq[c].z, v.z, o.z); o.w = fmaf(gq[c].w, v.w, o.w);
+                        *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + nq + 4 * c) = o;
+                    } else if constexpr (EPI == 2) {
+                        *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + nq + 4 * c) = v;
+                    } else {
+                        if (EPI == 5) { v.x = act_gelu_tanh(v.x); v.y = act_gelu_tanh(v.y); v.z = act_gelu_tanh(v.z); v.w = act_gelu_tanh(v.w); }
+                        if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
+                        if constexpr (RE) {
+                            if (rope_c >= 0) {                       // x-transformers apply_rotary_pos_emb on two interleaved pairs (epi_rope's arithmetic)
+                                rope_rotate(v, cur[c]);
+                            }
+                        }
+                        const bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
+                        pk[2 * c] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                        pk[2 * c + 1] = (uint32_t)h2 | ((uint32_t)h3 << 16);
+                        if constexpr (EPI == 4 || EPI == 5) {        // x = hi + lo as two bf16 planes for the next split-operand product
+                            pl[2 * c] = (uint32_t)f32_to_bf16(v.x - bf16_to_f32(h0)) | ((uint32_t)f32_to_bf16(v.y - bf16_to_f32(h1)) << 16);
+                            pl[2 * c + 1] = (uint32_t)f32_to_bf16(v.z - bf16_to_f32(h2)) | ((uint32_t)f32_to_bf16(v.w - bf16_to_f32(h3)) << 16);
+                        }
+                    }
+                }
+                if constexpr (EPI != 3 && EPI != 2) {
+                    bf16_t* o = (bf16_t*)e.out + (long)m * e.ldc + nq;
+                    *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    *reinterpret_cast<uint4*>(o + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+                    if constexpr (EPI == 4 || EPI == 5) {
+                        bf16_t* ol = (bf16_t*)e.out_lo + (long)m * e.ldc + nq;
+                        *reinterpret_cast<uint4*>(ol) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+                        *reinterpret_cast<uint4*>(ol + 8) = make_uint4(pl[4], pl[5], pl[6], pl[7]);
+                    }
+                }
+            }
+            if constexpr (PF && AHEAD) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
+            }
+        }
+        G2_STAMP(3);
+        return;
+    }
+    // epilogue through LDS, a quarter of the wave's tile (32 rows x 64 columns) at a time: see gemm_epilogue
+    float* park = reinterpret_cast<float*>(smem) + wid * 32 * 68;
+    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
+    const int n = n0 + wn * 64 + c4;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gv = bv;
+    if (e.bias) bv = *reinterpret_cast<const float4*>(e.bias + n);
+    if (EPI == 3) gv = *reinterpret_cast<const float4*>(e.gate + n);
+    // Rotary embedding (EPI 0): only the lanes whose four columns lie in a rotated range fetch (cos, sin) pairs, and they fetch
+    // a 32-row block's eight table rows in one batch, one block AHEAD of their use (under the previous block's stores) - fetched
+    // where they are used, each row's 16 bytes cost a trip to L2 in the middle of the store loop (qkv at M = 6400: +11 us on the
+    // 320x256 tile, whose epilogue nothing hides).
+    int rope_col = -1;                                              // float2 index of this lane's first pair inside a table row
+    if (RE && e.rope) {
+        const int nn = n >= e.rope_stride ? n - e.rope_stride : n;
+        if (n < 2 * e.rope_stride && nn < 2 * e.rope_half) rope_col = nn >> 1;
+    }
+    constexpr bool RAHEAD = AH;                             // the one-per-CU tiles have the registers for it; at 128 they would cost a workgroup per CU
+    float4 rt[8], rn[RAHEAD ? 8 : 1];
+    auto rope_fetch = [&](int mi, float4 (&t)[8]) {
+        if (rope_col < 0) return;
+        const int m00 = m0 + wm * (FM * 16) + mi * 32 + rsub;
+#pragma unroll
+        for (int it = 0; it < 8; ++it)
+            t[it] = *reinterpret_cast<const float4*>(e.rope + (long)((min(m00 + it * 4, M - 1) / e.rope_div) % e.rope_T) * e.rope_half + rope_col);
+    };
+    if (RE && RAHEAD) rope_fetch(0, rt);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        if (RE && !RAHEAD) rope_fetch(mi, rt);                   // before the block's trip through LDS
+        if constexpr (MF) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) park[(i * 16 + 4 * (lane >> 4) + r) * 68 + j * 16 + (lane & 15)] = acc4[2 * mi + i][j][r];
+        } else
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) park[((r & 3) + 8 * (r >> 2) + 4 * kh) * 68 + ni * 32 + lr] = acc[mi][ni][r];
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the wave reads back only its own quarter tile
+        __builtin_amdgcn_wave_barrier();
+        // the read-back is inline asm: in a kernel that uses the LDS DMA the compiler fences every LDS read it can see with
+        // vmcnt(0), which would make each quarter wait for the previous quarter's global stores to retire
+        f32x4 vq[8];
+        const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(park + rsub * 68 + c4);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vq[it]) : "v"(pa), "n"(it * 4 * 68 * 4) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vq[0]), "+v"(vq[1]), "+v"(vq[2]), "+v"(vq[3]), "+v"(vq[4]), "+v"(vq[5]), "+v"(vq[6]), "+v"(vq[7]) : : "memory");
+        float4 vr[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) vr[it] = make_float4(vq[it][0], vq[it][1], vq[it][2], vq[it][3]);
+        __builtin_amdgcn_wave_barrier();                         // the next quarter overwrites the park region
+        if constexpr (RE && RAHEAD) { if (mi + 1 < MI) rope_fetch(mi + 1, rn); }     // travels under this block's stores
+        const int mb = m0 + wm * (FM * 16) + mi * 32 + rsub;
+        float4 old[8];
+        if (EPI == 3) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int m = min(mb + it * 4, M - 1);
+                old[it] = *reinterpret_cast<const float4*>(e.resid + (long)m * e.ldc + n);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = mb + it * 4;
+            float4 v = vr[it];
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (m >= M) continue;
+            if (EPI == 3) {
+                float4 o = old[it];
+                o.x = fmaf(gv.x, v.x, o.x); o.y = fmaf(gv.y, v.y, o.y); o.z = fmaf(gv.z, v.z, o.z); o.w = fmaf(gv.w, v.w, o.w);
+                *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + n) = o;
+            } else if (EPI == 2) {
+                *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
+            } else if (EPI == 4 || EPI == 5) {
+                // fp32-class result for the next split-operand product: exact-tanh GELU (5) or the rotary embedding (4) on the fp32
+                // sums, then x = hi + lo as two bf16 planes
+                if (EPI == 5) { v.x = act_gelu_tanh(v.x); v.y = act_gelu_tanh(v.y); v.z = act_gelu_tanh(v.z); v.w = act_gelu_tanh(v.w); }
+                if (EPI == 4 && rope_col >= 0) {
+                    rope_rotate(v, rt[it]);
+                }
+                const bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
+                uint2 ph, pl;
+                ph.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                ph.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
+                pl.x = (uint32_t)f32_to_bf16(v.x - bf16_to_f32(h0)) | ((uint32_t)f32_to_bf16(v.y - bf16_to_f32(h1)) << 16);
+                pl.y = (uint32_t)f32_to_bf16(v.z - bf16_to_f32(h2)) | ((uint32_t)f32_to_bf16(v.w - bf16_to_f32(h3)) << 16);
+                *reinterpret_cast<uint2*>((bf16_t*)e.out + (long)m * e.ldc + n) = ph;
+                *reinterpret_cast<uint2*>((bf16_t*)e.out_lo + (long)m * e.ldc + n) = pl;
+            } else {
+                if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
+                if (EPI == 0 && rope_col >= 0) {                 // x-transformers apply_rotary_pos_emb on two interleaved pairs (epi_rope's arithmetic)
+                    rope_rotate(v, rt[it]);
+                }
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+                *reinterpret_cast<uint2*>((bf16_t*)e.out + (long)m * e.ldc + n) = pk;
+            }
+        }
+        if constexpr (RE && RAHEAD) {
+            if (rope_col >= 0) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) rt[it] = rn[it];
+            }
+        }
+    }
+    G2_STAMP(3);
+}
 
 // BN = 256: 8 waves as 2 (M) x 4 (N), 128x64 (BM 256) or 160x64 (BM 320) per wave.  BN = 128: 4 x 2 waves of 64x64, <= 128 VGPRs
 // and a 72 KB ring, so two workgroups are resident per CU: one's prologue / epilogue bursts run under the other's K loop (the
@@ -552,213 +775,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mi], fb[ks & 1][ni], acc[mi][ni], 0, 0, 0);
         }
     }
-    __syncthreads();                                                // all waves are done with the ring: the epilogue parks tiles in it
-    G2_STAMP(2);
-
-    constexpr bool RE = EPI == 0 || EPI == 4;                       // epilogues that may carry the rotary embedding
-    if constexpr (DE) {
-        // Direct epilogue: for 16-row tile i the lane holds row (lane & 15), columns nq .. nq + 15 as acc4[i][j][r] = column 4 j + r.
-        // The residual rows (EPI 3) or the rotary table rows (RE) of tile i + 1 are fetched before tile i is stored.
-        const int nq = n0 + wn * 64 + (lane >> 4) * 16, mw = m0 + wm * (MI * 32) + (lane & 15);
-        float4 bq[4], gq[EPI == 3 ? 4 : 1];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            bq[c] = e.bias ? *reinterpret_cast<const float4*>(e.bias + nq + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (EPI == 3) gq[c] = *reinterpret_cast<const float4*>(e.gate + nq + 4 * c);
-        }
-        int rope_c = -1;                                            // float2 index of the lane's first pair inside a table row
-        if (RE && e.rope) {
-            const int nn = nq >= e.rope_stride ? nq - e.rope_stride : nq;
-            if (nq < 2 * e.rope_stride && nn < 2 * e.rope_half) rope_c = nn >> 1;
-        }
-        constexpr bool PF = EPI == 3 || RE, AHEAD = BN == 256;      // the one-per-CU tiles have the registers to fetch a tile ahead, and nobody else to hide the trip
-        float4 cur[PF ? 4 : 1], nxt[PF && AHEAD ? 4 : 1];
-        auto fetch = [&](int i, auto& t) {
-            const int m = min(mw + i * 16, M - 1);
-            if constexpr (EPI == 3) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) t[c] = *reinterpret_cast<const float4*>(e.resid + (long)m * e.ldc + nq + 4 * c);
-            } else if constexpr (RE) {
-                if (rope_c >= 0) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) t[c] = *reinterpret_cast<const float4*>(e.rope + (long)((m / e.rope_div) % e.rope_T) * e.rope_half + rope_c + 2 * c);
-                }
-            }
-        };
-        if constexpr (PF && AHEAD) fetch(0, cur);
-#pragma unroll
-        for (int i = 0; i < 2 * MI; ++i) {
-            if constexpr (PF && AHEAD) { if (i + 1 < 2 * MI) fetch(i + 1, nxt); }
-            if constexpr (PF && !AHEAD) fetch(i, cur);
-            const int m = mw + i * 16;
-            if (m < M) {
-                uint32_t pk[8], pl[8];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float4 v = make_float4(acc4[i][c][0], acc4[i][c][1], acc4[i][c][2], acc4[i][c][3]);
-                    v.x += bq[c].x; v.y += bq[c].y; v.z += bq[c].z; v.w += bq[c].w;
-                    if constexpr (EPI == 3) {
-                        float4 o = cur[c];
-                        o.x = fmaf(gq[c].x, v.x, o.x); o.y = fmaf(gq[c].y, v.y, o.y); o.z = fmaf(gq[c].z, v.z, o.z); o.w = fmaf(gq[c].w, v.w, o.w);
-                        *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + nq + 4 * c) = o;
-                    } else if constexpr (EPI == 2) {
-                        *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + nq + 4 * c) = v;
-                    } else {
-                        if (EPI == 5) { v.x = act_gelu_tanh(v.x); v.y = act_gelu_tanh(v.y); v.z = act_gelu_tanh(v.z); v.w = act_gelu_tanh(v.w); }
-                        if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
-                        if constexpr (RE) {
-                            if (rope_c >= 0) {                       // x-transformers apply_rotary_pos_emb on two interleaved pairs (epi_rope's arithmetic)
-                                const float4 t = cur[c];
-                                const float a = v.x, b = v.y, cc = v.z, d = v.w;
-                                v.x = a * t.x - b * t.y; v.y = b * t.x + a * t.y;
-                                v.z = cc * t.z - d * t.w; v.w = d * t.z + cc * t.w;
-                            }
-                        }
-                        const bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
-                        pk[2 * c] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                        pk[2 * c + 1] = (uint32_t)h2 | ((uint32_t)h3 << 16);
-                        if constexpr (EPI == 4 || EPI == 5) {        // x = hi + lo as two bf16 planes for the next split-operand product
-                            pl[2 * c] = (uint32_t)f32_to_bf16(v.x - bf16_to_f32(h0)) | ((uint32_t)f32_to_bf16(v.y - bf16_to_f32(h1)) << 16);
-                            pl[2 * c + 1] = (uint32_t)f32_to_bf16(v.z - bf16_to_f32(h2)) | ((uint32_t)f32_to_bf16(v.w - bf16_to_f32(h3)) << 16);
-                        }
-                    }
-                }
-                if constexpr (EPI != 3 && EPI != 2) {
-                    bf16_t* o = (bf16_t*)e.out + (long)m * e.ldc + nq;
-                    *reinterpret_cast<uint4*>(o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                    *reinterpret_cast<uint4*>(o + 8) = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-                    if constexpr (EPI == 4 || EPI == 5) {
-                        bf16_t* ol = (bf16_t*)e.out_lo + (long)m * e.ldc + nq;
-                        *reinterpret_cast<uint4*>(ol) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-                        *reinterpret_cast<uint4*>(ol + 8) = make_uint4(pl[4], pl[5], pl[6], pl[7]);
-                    }
-                }
-            }
-            if constexpr (PF && AHEAD) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) cur[c] = nxt[c];
-            }
-        }
-        G2_STAMP(3);
-        return;
-    }
-    // epilogue through LDS, a quarter of the wave's tile (32 rows x 64 columns) at a time: see gemm_epilogue
-    float* park = reinterpret_cast<float*>(smem) + wid * 32 * 68;
-    const int c4 = (lane & 15) * 4, rsub = lane >> 4;
-    const int n = n0 + wn * 64 + c4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gv = bv;
-    if (e.bias) bv = *reinterpret_cast<const float4*>(e.bias + n);
-    if (EPI == 3) gv = *reinterpret_cast<const float4*>(e.gate + n);
-    // Rotary embedding (EPI 0): only the lanes whose four columns lie in a rotated range fetch (cos, sin) pairs, and they fetch
-    // a 32-row block's eight table rows in one batch, one block AHEAD of their use (under the previous block's stores) - fetched
-    // where they are used, each row's 16 bytes cost a trip to L2 in the middle of the store loop (qkv at M = 6400: +11 us on the
-    // 320x256 tile, whose epilogue nothing hides).
-    int rope_col = -1;                                              // float2 index of this lane's first pair inside a table row
-    if (RE && e.rope) {
-        const int nn = n >= e.rope_stride ? n - e.rope_stride : n;
-        if (n < 2 * e.rope_stride && nn < 2 * e.rope_half) rope_col = nn >> 1;
-    }
-    constexpr bool RAHEAD = BN == 256;                             // the one-per-CU tiles have the registers for it; at 128 they would cost a workgroup per CU
-    float4 rt[8], rn[RAHEAD ? 8 : 1];
-    auto rope_fetch = [&](int mi, float4 (&t)[8]) {
-        if (rope_col < 0) return;
-        const int m00 = m0 + wm * (MI * 32) + mi * 32 + rsub;
-#pragma unroll
-        for (int it = 0; it < 8; ++it)
-            t[it] = *reinterpret_cast<const float4*>(e.rope + (long)((min(m00 + it * 4, M - 1) / e.rope_div) % e.rope_T) * e.rope_half + rope_col);
-    };
-    if (RE && RAHEAD) rope_fetch(0, rt);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        if (RE && !RAHEAD) rope_fetch(mi, rt);                   // before the block's trip through LDS
-        if constexpr (MF) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) park[(i * 16 + 4 * (lane >> 4) + r) * 68 + j * 16 + (lane & 15)] = acc4[2 * mi + i][j][r];
-        } else
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) park[((r & 3) + 8 * (r >> 2) + 4 * kh) * 68 + ni * 32 + lr] = acc[mi][ni][r];
-        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the wave reads back only its own quarter tile
-        __builtin_amdgcn_wave_barrier();
-        // the read-back is inline asm: in a kernel that uses the LDS DMA the compiler fences every LDS read it can see with
-        // vmcnt(0), which would make each quarter wait for the previous quarter's global stores to retire
-        f32x4 vq[8];
-        const uint32_t pa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const float*)(park + rsub * 68 + c4);
-#pragma unroll
-        for (int it = 0; it < 8; ++it) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vq[it]) : "v"(pa), "n"(it * 4 * 68 * 4) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(vq[0]), "+v"(vq[1]), "+v"(vq[2]), "+v"(vq[3]), "+v"(vq[4]), "+v"(vq[5]), "+v"(vq[6]), "+v"(vq[7]) : : "memory");
-        float4 vr[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) vr[it] = make_float4(vq[it][0], vq[it][1], vq[it][2], vq[it][3]);
-        __builtin_amdgcn_wave_barrier();                         // the next quarter overwrites the park region
-        if constexpr (RE && RAHEAD) { if (mi + 1 < MI) rope_fetch(mi + 1, rn); }     // travels under this block's stores
-        const int mb = m0 + wm * (MI * 32) + mi * 32 + rsub;
-        float4 old[8];
-        if (EPI == 3) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int m = min(mb + it * 4, M - 1);
-                old[it] = *reinterpret_cast<const float4*>(e.resid + (long)m * e.ldc + n);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int m = mb + it * 4;
-            float4 v = vr[it];
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-            if (m >= M) continue;
-            if (EPI == 3) {
-                float4 o = old[it];
-                o.x = fmaf(gv.x, v.x, o.x); o.y = fmaf(gv.y, v.y, o.y); o.z = fmaf(gv.z, v.z, o.z); o.w = fmaf(gv.w, v.w, o.w);
-                *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + n) = o;
-            } else if (EPI == 2) {
-                *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
-            } else if (EPI == 4 || EPI == 5) {
-                // fp32-class result for the next split-operand product: exact-tanh GELU (5) or the rotary embedding (4) on the fp32
-                // sums, then x = hi + lo as two bf16 planes
-                if (EPI == 5) { v.x = act_gelu_tanh(v.x); v.y = act_gelu_tanh(v.y); v.z = act_gelu_tanh(v.z); v.w = act_gelu_tanh(v.w); }
-                if (EPI == 4 && rope_col >= 0) {
-                    const float4 t = rt[it];
-                    const float a = v.x, b = v.y, c = v.z, d = v.w;
-                    v.x = a * t.x - b * t.y; v.y = b * t.x + a * t.y;
-                    v.z = c * t.z - d * t.w; v.w = d * t.z + c * t.w;
-                }
-                const bf16_t h0 = f32_to_bf16(v.x), h1 = f32_to_bf16(v.y), h2 = f32_to_bf16(v.z), h3 = f32_to_bf16(v.w);
-                uint2 ph, pl;
-                ph.x = (uint32_t)h0 | ((uint32_t)h1 << 16);
-                ph.y = (uint32_t)h2 | ((uint32_t)h3 << 16);
-                pl.x = (uint32_t)f32_to_bf16(v.x - bf16_to_f32(h0)) | ((uint32_t)f32_to_bf16(v.y - bf16_to_f32(h1)) << 16);
-                pl.y = (uint32_t)f32_to_bf16(v.z - bf16_to_f32(h2)) | ((uint32_t)f32_to_bf16(v.w - bf16_to_f32(h3)) << 16);
-                *reinterpret_cast<uint2*>((bf16_t*)e.out + (long)m * e.ldc + n) = ph;
-                *reinterpret_cast<uint2*>((bf16_t*)e.out_lo + (long)m * e.ldc + n) = pl;
-            } else {
-                if (EPI == 1) { v.x = act_gelu_tanh_fast(v.x); v.y = act_gelu_tanh_fast(v.y); v.z = act_gelu_tanh_fast(v.z); v.w = act_gelu_tanh_fast(v.w); }
-                if (EPI == 0 && rope_col >= 0) {                 // x-transformers apply_rotary_pos_emb on two interleaved pairs (epi_rope's arithmetic)
-                    const float4 t = rt[it];
-                    const float a = v.x, b = v.y, c = v.z, d = v.w;
-                    v.x = a * t.x - b * t.y; v.y = b * t.x + a * t.y;
-                    v.z = c * t.z - d * t.w; v.w = d * t.z + c * t.w;
-                }
-                uint2 pk;
-                pk.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-                pk.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
-                *reinterpret_cast<uint2*>((bf16_t*)e.out + (long)m * e.ldc + n) = pk;
-            }
-        }
-        if constexpr (RE && RAHEAD) {
-            if (rope_col >= 0) {
-#pragma unroll
-                for (int it = 0; it < 8; ++it) rt[it] = rn[it];
-            }
-        }
-    }
-    G2_STAMP(3);
+    ring_epilogue<EPI, BN, 2 * MI, MF, DE, BN == 256>(smem, acc, acc4, e, M, N, m0, n0, wm, wn, wid, lane);
 }
 
 template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0, int SP = 0>
@@ -772,6 +789,171 @@ static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int
     }
     dim3 grid((N / BN) * cdiv(M, BM));
     hipLaunchKernelGGL((gemm256_k<EPI, BN, BM, STAG, MF, SP>), grid, dim3(BM == 128 ? 256 : 512), lds, st, A, lda, W, M, N, K, epi);
+    HIP_TRY(hipGetLastError());
+    return FY_OK;
+}
+
+// ---- the 64-deep, register-staged kernel (round 5) ----------------------------------------------------------------------------
+// What bounds gemm256_k at the DiT shapes is its OPERAND FETCH, not the matrix cores (tests/micro/fetch_rows.hip, profiles/
+// r05_gemm_fetch_bound.txt): its staging traffic alone - global -> LDS by LDS-DMA, no MFMAs - takes about as long as the whole kernel.
+// The LDS-DMA path of a CU saturates near 18-24 bytes per clock (10-14 TB/s chip-wide) whether the lines hit L2 or not, whatever the
+// ring depth; plain 16-byte loads to REGISTERS of the same lines run at 17.3 TB/s with one workgroup per CU.  So this kernel
+//   (1) stages through registers: a thread loads its 64 bytes of stage t + 2 (global_load_dwordx4 x 4, whole 128-byte lines per
+//       8 lanes) while stage t is being multiplied, and writes them to the other LDS buffer (ds_write_b128) one stage later - two
+//       stages of lookahead, one of them in registers, where two LDS-DMA stages of this size were all 160 KB hold;
+//   (2) uses 64-deep stages of a 256 x 256 tile: a line is requested once (the 32-deep ring asks for its halves in two stages) and
+//       ff1 stages 210 MB where two 256 x 128 tiles per CU stage 315;
+//   (3) runs SIXTEEN waves (4 x 4, each 64 rows x 64 columns, <= 128 registers) as the one workgroup of its CU: four waves per SIMD
+//       hide each other's fragment reads and barrier skew as two workgroups per CU did, without a second copy of the operands.
+//   * LDS: two buffers of [BM + BN rows][128 B]; chunk c (16 B) of row r sits at slot c ^ SW(r): conflict-free for the 16x16x32
+//     fragment reads (16 rows x one chunk per 16 lanes; the direct epilogue's 4-rows-of-every-16 B pattern) and for the stores
+//     (8 lanes = one row's 128 bytes).
+//   * K order per accumulator: 32-deep sub-steps in ascending k, exactly gemm256_k's - outputs are bit-identical to its tilings'.
+#ifndef G64_SPREAD
+#define G64_SPREAD 0          // staging spread over the MFMA groups instead of in one block between the sub-steps: measured 1-5 % slower (ff1 35.1-36.1 against 34.3-34.7 us)
+#endif
+#ifndef G64_ABL
+#define G64_ABL 0          // ablations for tests/micro/gemm_bench (never in the library): 1 no MFMAs, 2 no global loads, 3 no fragment reads
+#endif
+// NWAVE = 16: 4 x 4 waves of (BM / 4) x 64 (BM = 256: the 128-register form above).  NWAVE = 8: 2 x 4 waves of (BM / 2) x 64 with up to
+// 256 registers - for BM = 320 (qkv at M = 6400: 240 tiles = one round where 256-row tiles need a second one), whose 80-row wave
+// tiles do not fit 128 registers.
+// BN = 128 (the N = 1024 products, out-projection and ff2, at M = 6400: 200 tiles of 256 x 128): 8 x 2 waves of 32 x 64, the gated
+// fp32 residual through the LDS epilogue (its 256-byte row runs; the LDS allocation is the epilogue's 136 KB of parked tiles).
+template <int EPI, int BM, int BN, int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64) void gemm64_k(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
+    extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
+    char* smem = reinterpret_cast<char*>(gm_smem);
+    constexpr int NT = NWAVE * 64;
+    static_assert((NWAVE == 16 && BM == 256 && (BN == 256 || BN == 128)) || (NWAVE == 8 && BN == 256 && (BM == 256 || BM == 320)),
+                  "gemm64_k: 256x256 (8 or 16 waves), 256x128 (16 waves) and 320x256 (8 waves) tiles");
+    constexpr int WN = BN / 64, WM = NWAVE / WN, FM = BM / WM / 16;       // FM 16-row tiles x 4 column tiles per wave
+    constexpr bool DE = EPI != 2 && EPI != 3;                             // bf16 outputs: the direct epilogue (transposed products)
+    constexpr bool SPREAD = G64_SPREAD && NWAVE == 16;                   // (the 320-row form has no register to spare for it)
+    constexpr int STAGE = (BM + BN) * 128, BOFF = BM * 128;
+    constexpr int NLA = BM * 8 / NT, NLB = BN * 8 / NT, NL = NLA + NLB;      // 16-byte loads per thread and stage: A rows, W rows
+    static_assert(NLA * NT == BM * 8, "whole loads");
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid / WN, wn = wid % WN;
+    auto SW = [](int row) -> int { return ((row >> 1) ^ ((row >> 4) << 1)) & 7; };
+    const int ntn = N / BN, nwg = gridDim.x;
+    const int orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
+    G2_STAMP(0);
+    // staging: load i of a thread is chunk (tid & 7) of row (tid >> 3) + 128 i of the stage (rows 0 .. BM-1: A, then W).  Sources as a
+    // wave-uniform base + one 32-bit byte offset per load (64-bit pointers would not fit the 128 registers), destination offset in LDS
+    const char* const Abase = reinterpret_cast<const char*>(A + (long)m0 * lda);
+    const char* const Wbase = reinterpret_cast<const char*>(W + (long)n0 * K);
+    uint32_t g_off[NL], l_off[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        const int row = (tid >> 3) + (NT / 8) * i, c = tid & 7;
+        if (i < NLA) g_off[i] = (uint32_t)(min(row, M - 1 - m0) * lda + c * 8) * 2u;
+        else g_off[i] = (uint32_t)(min(row - BM, N - 1 - n0) * K + c * 8) * 2u;
+        l_off[i] = row * 128 + ((c ^ SW(row)) << 4);
+    }
+    static_assert(NL <= 9, "nine staging registers");
+    uint4 rs0, rs1, rs2, rs3, rs4, rs5, rs6, rs7, rs8;                   // (named: as an array, however it was indexed, this ended up in scratch memory)
+    // (the empty asm keeps base + offset from being hoisted out of the K loop as 64-bit pairs, which would not fit the registers)
+#define G64_L(k, t) if constexpr (NL > k) { uint32_t o_ = g_off[k]; asm volatile("" : "+v"(o_)); rs##k = *reinterpret_cast<const uint4*>((k < NLA ? Abase : Wbase) + (t) * 128 + (size_t)o_); }
+#define G64_S(k, t) if constexpr (NL > k) { *reinterpret_cast<uint4*>(smem + ((t) & 1) * STAGE + l_off[k]) = rs##k; }
+#define G64_LOAD_STAGE(t) G64_L(0, t) G64_L(1, t) G64_L(2, t) G64_L(3, t) G64_L(4, t) G64_L(5, t) G64_L(6, t) G64_L(7, t) G64_L(8, t)
+#define G64_STORE_STAGE(t) G64_S(0, t) G64_S(1, t) G64_S(2, t) G64_S(3, t) G64_S(4, t) G64_S(5, t) G64_S(6, t) G64_S(7, t) G64_S(8, t)
+    f32x4 acc4[FM][4];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Fragment read addresses, ONE register per operand (the 128-register cap again).  A fragment i: row ra = wm FM 16 + 16 i + (lane & 15),
+    // chunk (lane >> 4) + 4 ks, slot = chunk ^ SW(ra), and SW(ra) = ((lane & 15) >> 1) ^ (((wm FM + i) << 1) & 7): the lane's part and
+    // a wave-uniform part, so address = [la: the lane's part] ^ [xa(i) ^ 64 ks: uniform, low 7 bits] + 2048 i.  B fragment j (the direct
+    // epilogue's dealing of W rows to the column tiles): row rb = wn 64 + 16 ((lane & 15) >> 2) + 4 j + (lane & 3), SW(rb) = (2 j) ^ [lane's
+    // part], address = [lb] ^ (32 j ^ 64 ks) + 512 j.  (All of it modulo a 128-byte aligned LDS base: checked below.)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    if (lds0 & 127) __builtin_trap();
+    const int q16 = lane >> 4, l15 = lane & 15;
+    const uint32_t la = lds0 + (wm * (FM * 16) + l15) * 128 + ((q16 ^ (l15 >> 1)) << 4);
+    // (without the direct epilogue the B fragments are plain 16-row tiles like A's: row wn 64 + 16 j + (lane & 15), address = [lb] ^ (32 j ^ 64 ks) + 2048 j)
+    const uint32_t lb = DE ? lds0 + BOFF + (wn * 64 + (l15 >> 2) * 16 + (lane & 3)) * 128 + ((q16 ^ ((lane >> 1) & 1) ^ ((l15 >> 2) << 1)) << 4)
+                           : lds0 + BOFF + (wn * 64 + l15) * 128 + ((q16 ^ (l15 >> 1)) << 4);
+    auto xa = [&](int i) -> uint32_t { return (uint32_t)((((wm * FM + i) << 1) & 7) << 4); };       // wave-uniform (a constant when FM = 4)
+    const int nt = K / 64;
+    // one 32-deep sub-step of stage t: the fragment reads are inline asm issued two A fragments ahead of their use (24 fragment
+    // registers live instead of 32); reads return in order, so group g waits until at most one read is outstanding
+    auto sub_step = [&](int t, int ks) {
+        const uint32_t va = la + (t & 1) * STAGE, vb = lb + (t & 1) * STAGE;
+        f32x4 rb[4], ra[FM];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { if (G64_ABL == 3) rb[j] = f32x4{1.f, 1.f, 1.f, 1.f}; else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rb[j]) : "v"(vb ^ (uint32_t)((j * 32) ^ (ks * 64))), "n"(DE ? j * 512 : j * 2048)); }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { if (G64_ABL == 3) ra[i] = f32x4{1.f, 1.f, 1.f, 1.f}; else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra[i]) : "v"(va ^ (xa(i) ^ (uint32_t)(ks * 64))), "n"(i * 2048)); }
+#pragma unroll
+        for (int g = 0; g < FM; ++g) {
+            if (g + 1 < FM) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(ra[g]));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(ra[g]));
+            if (g + 2 < FM) { if (G64_ABL == 3) ra[g + 2] = f32x4{1.f, 1.f, 1.f, 1.f}; else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra[g + 2]) : "v"(va ^ (xa(g + 2) ^ (uint32_t)(ks * 64))), "n"((g + 2) * 2048)); }
+            const frag_ab fa_g = __builtin_bit_cast(frag_ab, ra[g]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { if (G64_ABL == 1) acc4[g][j][0] += rb[j][0] + ra[g][0]; else acc4[g][j] = DE ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_ab, rb[j]), fa_g, acc4[g][j], 0, 0, 0)
+                                                                                                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_g, __builtin_bit_cast(frag_ab, rb[j]), acc4[g][j], 0, 0, 0); }
+            // Staging, one register per MFMA group of the FIRST sub-step (G64_SPREAD): register k holds its 16 bytes of stage t + 1
+            // (requested a stage ago) - into the other buffer (last read during stage t - 1, which every wave has left: the barrier),
+            // and its load of stage t + 2 goes out at once.  Spread over the groups, the 16 waves' stores and loads do not arrive
+            // at the LDS and the memory pipe as one burst.
+            if (SPREAD && ks == 0) {
+                const bool st_ok = t + 1 < nt;
+                const int tl = min(t + 2, nt - 1);
+                switch (g) {
+                    case 0: if (st_ok) { G64_S(0, t + 1) } if (G64_ABL != 2) { G64_L(0, tl) } if (FM == 5 || FM == 10) { if (st_ok) { G64_S(8, t + 1) } if (G64_ABL != 2) { G64_L(8, tl) } } break;
+                    case 1: if (st_ok) { G64_S(1, t + 1) } if (G64_ABL != 2) { G64_L(1, tl) } break;
+                    case 2: if (st_ok) { G64_S(2, t + 1) } if (G64_ABL != 2) { G64_L(2, tl) } break;
+                    case 3: if (st_ok) { G64_S(3, t + 1) } if (G64_ABL != 2) { G64_L(3, tl) } break;
+                    case 4: if (st_ok) { G64_S(4, t + 1) } if (G64_ABL != 2) { G64_L(4, tl) } break;
+                    case 5: if (st_ok) { G64_S(5, t + 1) } if (G64_ABL != 2) { G64_L(5, tl) } break;
+                    case 6: if (st_ok) { G64_S(6, t + 1) } if (G64_ABL != 2) { G64_L(6, tl) } break;
+                    case 7: if (st_ok) { G64_S(7, t + 1) } if (G64_ABL != 2) { G64_L(7, tl) } break;
+                    default: break;
+                }
+            }
+        }
+    };
+    { G64_LOAD_STAGE(0) }
+    { G64_STORE_STAGE(0) }
+    { G64_LOAD_STAGE(min(1, nt - 1)) }
+    __syncthreads();
+    G2_STAMP(1);
+    for (int t = 0; t < nt; ++t) {
+        sub_step(t, 0);
+        // the registers hold stage t + 1 (requested a stage ago): into the other buffer - last read during stage t - 1, which every wave
+        // has left (the barrier below) - and the loads of stage t + 2 go out at once (unconditional, clamped: no copies at a join)
+        if (!SPREAD) {
+            if (t + 1 < nt) { G64_STORE_STAGE(t + 1) }
+            if (G64_ABL != 2) { G64_LOAD_STAGE(min(t + 2, nt - 1)) }
+        }
+        sub_step(t, 1);
+        __syncthreads();
+    }
+#undef G64_L
+#undef G64_S
+#undef G64_LOAD_STAGE
+#undef G64_STORE_STAGE
+    f32x16 acc_unused[(FM + 1) / 2][2];
+    ring_epilogue<EPI, BN, FM, 1, DE, NWAVE == 8>(smem, acc_unused, acc4, e, M, N, m0, n0, wm, wn, wid, lane);
+}
+
+template <int EPI, int BM, int BN, int NWAVE>
+static int gemm_launch_64(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
+    static PerDeviceOnce attr_once;
+    // two buffers: 2 x 64 KB (256x256), 2 x 72 KB (320x256), 2 x 48 KB (256x128) - or what the LDS epilogue parks (a 32 x 64 fp32 tile per wave)
+    const size_t lds = std::max((size_t)2 * (BM + BN) * 128, (EPI == 2 || EPI == 3) ? (size_t)NWAVE * 32 * 68 * 4 : (size_t)0);
+    const int dslot = current_device_slot();
+    if (!attr_once.done[dslot].load(std::memory_order_acquire)) {
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm64_k<EPI, BM, BN, NWAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_once.done[dslot].store(true, std::memory_order_release);
+    }
+    dim3 grid((N / BN) * cdiv(M, BM));
+    hipLaunchKernelGGL((gemm64_k<EPI, BM, BN, NWAVE>), grid, dim3(NWAVE * 64), lds, st, A, lda, W, M, N, K, epi);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -829,6 +1011,24 @@ static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, i
         if (ov == 2) return gemm_launch_256<EPI, 128>(Ab, lda, W, M, N, K, epi, st);
         if (ov == 3) return gemm_launch_256<EPI, 128, 128>(Ab, lda, W, M, N, K, epi, st);
         const int t128 = (N / 128) * cdiv(M, 256), t64 = (N / 128) * cdiv(M, 128), t320 = N % 256 ? 0 : (N / 256) * cdiv(M, 320);
+        // Round 5: the 64-deep ring with ONE 256x256 or 320x256 tile of sixteen waves per CU for the bf16-output products whose tiles
+        // cover the chip in one round (ff1 at M = 6400: 200 tiles; qkv: 240) - gemm64_k's comment says why.  FY_GEMM64=0: off.
+        static const int g64 = getenv("FY_GEMM64") ? atoi(getenv("FY_GEMM64")) : 1;
+        if constexpr (EPI == 0 || EPI == 1) {
+            if ((ov == 6400 || ov == 6408 || ov == 6432 || (ov == 0 && g64)) && N % 256 == 0 && K % 64 == 0) {
+                const int t256 = (N / 256) * cdiv(M, 256);
+                if (ov == 6400 || (ov == 0 && t256 <= cus && 20 * t256 >= 15 * cus)) return gemm_launch_64<EPI, 256, 256, 16>(Ab, lda, W, M, N, K, epi, st);
+                if (ov == 6408) return gemm_launch_64<EPI, 256, 256, 8>(Ab, lda, W, M, N, K, epi, st);
+                if (ov == 6432 || (ov == 0 && t320 <= cus && 20 * t320 >= 15 * cus)) return gemm_launch_64<EPI, 320, 256, 8>(Ab, lda, W, M, N, K, epi, st);
+            }
+        }
+        if constexpr (EPI == 3) {
+            // the gated fp32 residual products (out-projection, ff2) as 256 x 128 tiles of 16 waves, one per CU: measured, NOT chosen
+            // (override 6412 only).  Its K loop takes what the 128 x 128 LDS-DMA tiles' takes (15.6 against 15.4 us for the
+            // out-projection, 31.9 against 30.6 for ff2): sixteen 32 x 64 wave tiles read 0.75 fragments per MFMA and, with the staging
+            // stores, the LDS array is busier than the matrix cores - and one tile per CU has nothing to run under its epilogue.
+            if (ov == 6412 && K % 64 == 0) return gemm_launch_64<EPI, 256, 128, 16>(Ab, lda, W, M, N, K, epi, st);
+        }
         // 320x256 tiles, one workgroup per CU, when they cover the chip in ONE round where 256x128 tiles would need a second one
         if (ov == 1320 && N % 256 == 0) return gemm_launch_256<EPI, 256, 320, 1>(Ab, lda, W, M, N, K, epi, st);
         if (ov == 0 && t128 > 2 * cus && t320 <= cus && 20 * t320 >= 17 * cus) return gemm_launch_256<EPI, 256, 320, 1, 1>(Ab, lda, W, M, N, K, epi, st);

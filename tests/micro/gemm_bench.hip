@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
         for (auto& s : shapes) {
             if (s.mode != 0) continue;
             std::vector<bf16_t> ref((size_t)s.M * s.N), got(ref.size());
-            for (int tile : {0, 256, 320, 1256, 1320, 2002, 2003, 2256, 3320, 3256, 2, 3, 128}) {
+            for (int tile : {0, 256, 320, 1256, 1320, 2002, 2003, 2256, 3320, 3256, 2, 3, 128, 6400, 6408, 6432}) {     // 6400 / 6432: gemm64_k, 256x256 / 320x256 (run with FY_GEMM64=0 so that tile 0 is the 32-deep ring)
                 if (tile >= 256 && tile < 2000 && s.N % 256) continue;
                 gemm_tile_override = tile;
                 GemmEpi e; e.bias = bias; e.out = O; e.out_bf16 = 1; e.ldc = s.N; e.act = s.N == 2048 ? ACT_GELU_TANH : ACT_NONE;
@@ -62,13 +62,38 @@ int main(int argc, char** argv) {
                     size_t bad = 0; double maxd = 0;
                     auto f = [](bf16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
                     for (size_t i = 0; i < ref.size(); ++i) { bad += ref[i] != got[i]; maxd = std::max(maxd, (double)fabsf(f(ref[i]) - f(got[i]))); }
-                    if (tile >= 2000 && tile != 3320 && tile != 3256 && tile != 2256) { printf("check %-20s tile %4d (16x16x32 MFMA: another summation order inside the instruction): %zu of %zu outputs differ by at most %.3g\n", s.name, tile, bad, ref.size(), maxd); continue; }
+                    if (tile >= 2000 && tile != 3320 && tile != 3256 && tile != 2256 && tile != 6432 && tile != 6400 && tile != 6408) { printf("check %-20s tile %4d (16x16x32 MFMA: another summation order inside the instruction): %zu of %zu outputs differ by at most %.3g\n", s.name, tile, bad, ref.size(), maxd); continue; }
                     printf("check %-20s M %5d N %4d K %4d tile %3d: %zu of %zu outputs differ from the automatic tiling%s\n", s.name, s.M, s.N, s.K, tile, bad, ref.size(), bad ? "  <-- MISMATCH" : "");
                 }
             }
         }
     }
-    for (int tile : {0, 2002, 2003, 1320, 3320, 2256, 3256}) {   // + 3320 / 3256: staggered 320x256 / 256x256 on 16x16x32; 2256: 256x256 plain
+    if (!pmc) {   // the gated fp32 residual products: resid += gate * (acc + bias) from zero, every tiling against the automatic choice, bit for bit
+        std::vector<float> gv(Nmax);
+        for (int i = 0; i < Nmax; ++i) gv[i] = 0.25f + 0.001f * (i % 97);
+        float* gate; hipMalloc(&gate, Nmax * 4); hipMemcpy(gate, gv.data(), Nmax * 4, hipMemcpyHostToDevice);
+        for (auto& s : shapes) {
+            if (s.mode != 1) continue;
+            std::vector<float> ref((size_t)s.M * s.N), got(ref.size());
+            for (int tile : {0, 3, 2003, 6412}) {
+                gemm_tile_override = tile;
+                GemmEpi e; e.bias = gate; e.mode = EPI_GATE_RESID; e.resid = R; e.gate = gate; e.ldc = s.N;
+                hipMemsetAsync(R, 0, ref.size() * 4, st);
+                gemm_bf16(A, s.K, W, s.M, s.N, s.K, e, st);
+                gemm_bf16(A, s.K, W + (size_t)Nmax * Kmax, s.M, s.N, s.K, e, st);          // a second accumulation on top: the read-modify-write path
+                hipStreamSynchronize(st);
+                hipMemcpy(tile ? got.data() : ref.data(), R, ref.size() * 4, hipMemcpyDeviceToHost);
+                if (tile) {
+                    size_t bad = 0;
+                    for (size_t i = 0; i < ref.size(); ++i) bad += memcmp(&ref[i], &got[i], 4) != 0;
+                    printf("check %-20s M %5d N %4d K %4d tile %4d: %zu of %zu fp32 outputs differ from the automatic tiling%s\n", s.name, s.M, s.N, s.K, tile, bad, ref.size(), bad ? "  <-- MISMATCH" : "");
+                }
+            }
+        }
+        hipMemsetAsync(R, 0, (size_t)Mmax * Nmax * 4, st);
+        hipStreamSynchronize(st);
+    }
+    for (int tile : {0, 6400, 6408, 6432, 6412, 2002, 2003, 1320, 3320, 2256, 3256}) {   // + 3320 / 3256: staggered 320x256 / 256x256 on 16x16x32; 2256: 256x256 plain
         if (pmc && tile) continue; gemm_tile_override = tile; printf("--- tile override %d (0: automatic choice; 2 / 3: LDS-DMA ring with 256x128 / 128x128 tiles; 2002 / 2003: the same on 16x16x32 MFMAs; 1320: 320x256 tiles, staggered wave groups)\n", tile);
     for (auto& s : shapes) {
         GemmEpi e;

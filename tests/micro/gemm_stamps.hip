@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
     hipMalloc(&sb, SB * 8); hipMemset(sb, 0, SB * 8);
     struct S { int N, K; int mode; const char* name; } shapes[] = {{3072, 1024, 0, "qkv"}, {1024, 1024, 1, "out"}, {2048, 1024, 0, "ff1"}, {1024, 2048, 1, "ff2"}};
     extern int gemm_tile_override;
-    for (int tile : {0, 3320, 3256}) {
+    for (int tile : {0, 6400, 6412, 6432, 3320}) {      // run with FY_GEMM64=0: tile 0 = the 32-deep ring, 6400 = gemm64_k
         gemm_tile_override = tile;
         auto block = [&](bool stamp) {
             int slot = 0;
