@@ -35,6 +35,15 @@ struct fy_flow {
     float* ones = nullptr;     // [dim] ones (the gate of a lo-plane pass that adds into an fp32 output)
     float *b_in, *b_out, *b_t0, *b_t2, *b_fin;
     std::vector<FlowBlockW> blk;
+    // LayerNorm-modulate folded across the qkv / ff1 products (round 5; dit_forward says when): per (Euler step, block) the weights
+    // W' = bf16(W (1 + scale)), u[n] = sum_k W'[n][k] and bias' = bias + W shift - the modulation depends on the step only, so all of
+    // it is made once at create (2.2 GB at full size) - and, per call, bf16(h) with its per-(row, 64-column tile) sums from the
+    // producing product's epilogue (hb, ln_slots)
+    bool fold = false;
+    bf16_t *wq_fold = nullptr, *w1_fold = nullptr;       // [n_steps][depth][3 inner][dim], [n_steps][depth][ff][dim]
+    float *uq_fold = nullptr, *bq_fold = nullptr, *u1_fold = nullptr, *b1_fold = nullptr;      // [n_steps][depth][3 inner] / [ff]
+    bf16_t* hb = nullptr;
+    float2* ln_slots = nullptr;
     float* mod = nullptr;      // [(n_steps+1)][depth][6*dim]   (slot n_steps = scratch for fy_dit_estimator)
     float* fin = nullptr;      // [(n_steps+1)][2*dim]
     float2* rope = nullptr;    // [Tmax][head_dim/2] (cos, sin)
@@ -254,6 +263,29 @@ static int lo_plane(fy_flow* f, const float* src, int N, int K, bool packed, bf1
     return rc;
 }
 
+// One row n of a folded product (gemm.h: GemmEpi::ln_rows): W'[n][k] = bf16(W[n][k] (1 + scale[k])), u[n] = sum_k W'[n][k] (of the ROUNDED
+// values: the mean term then cancels exactly), bias'[n] = bias[n] + sum_k W[n][k] shift[k].  One block per row, sums in double.
+__global__ __launch_bounds__(256) void fold_row_k(const float* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ scale,
+                                                  const float* __restrict__ shift, bf16_t* __restrict__ Wp, float* __restrict__ u, float* __restrict__ bp, int K) {
+    __shared__ double su[256], sv[256];
+    const int n = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float w = W[(long)n * K + k];
+        const bf16_t q = f32_to_bf16(w * (1.f + scale[k]));
+        Wp[(long)n * K + k] = q;
+        a += (double)bf16_to_f32(q);
+        b += (double)w * (double)shift[k];
+    }
+    su[threadIdx.x] = a; sv[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { su[threadIdx.x] += su[threadIdx.x + o]; sv[threadIdx.x] += sv[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { u[n] = (float)su[0]; bp[n] = (float)((double)bias[n] + sv[0]); }
+}
+
 // modulation vectors of one set of timesteps: slot0.. (rows = n), see modules.py:606-616, 239-241, 260-261
 static int compute_mod(fy_flow* f, const float* t_host, int n, int slot0, hipStream_t st) {
     const fy_flow_config& c = f->cfg;
@@ -388,6 +420,8 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
         TRYC(conv_pack(f->pos2, c2w, nullptr, c2b, D, D, c.conv_pos_k, c.conv_pos_groups, true, mf, st));
     }
     f->blk.resize(c.depth);
+    struct FoldSrc { const float *qw, *kw, *vw, *f1w; };
+    std::vector<FoldSrc> fsrc(c.depth);
     for (int i = 0; i < c.depth; ++i) {
         const std::string b = E + "transformer_blocks." + std::to_string(i) + ".";
         FlowBlockW& k = f->blk[i];
@@ -399,6 +433,7 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
         GETW(ow, b + "attn.to_out.0.weight", D, inner); GETW(ob, b + "attn.to_out.0.bias", D);
         GETW(f1w, b + "ff.ff.0.0.weight", FF, D); GETW(f1b, b + "ff.ff.0.0.bias", FF);
         GETW(f2w, b + "ff.ff.2.weight", D, FF); GETW(f2b, b + "ff.ff.2.bias", D);
+        fsrc[i] = FoldSrc{qw, kw, vw, f1w};
         TRYC(to_packed(f, mw, 6 * D, D, &k.wmod, st)); TRYC(copy_f32(f, mb, 6 * D, &k.bmod, st));
         TRYC(f->pool.alloc(&k.wqkv, (size_t)3 * inner * D));
         TRYC(f->pool.alloc(&k.bqkv, (size_t)3 * inner));
@@ -441,6 +476,7 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
     TRYC(f->pool.alloc(&f->v, M * C)); TRYC(f->pool.alloc(&f->temb, (size_t)16 * D * 3)); TRYC(f->pool.alloc(&f->tsil, (size_t)16 * D));
     TRYC(f->pool.alloc(&f->a_in, M * 4 * C)); TRYC(f->pool.alloc(&f->xn, M * D)); TRYC(f->pool.alloc(&f->qkv, M * 3 * inner));
     TRYC(f->pool.alloc(&f->ao, M * inner)); TRYC(f->pool.alloc(&f->ff, M * FF));
+    TRYC(f->pool.alloc(&f->hb, M * D)); TRYC(f->pool.alloc(&f->ln_slots, M * (D / 64)));
     TRYC(f->pool.alloc(&f->mod, (size_t)(c.n_timesteps + 1) * c.depth * 6 * D));
     TRYC(f->pool.alloc(&f->fin, (size_t)(c.n_timesteps + 1) * 2 * D));
     TRYC(f->pool.alloc(&f->rope, T * (c.head_dim / 2)));
@@ -469,6 +505,33 @@ extern "C" int fy_flow_create(fy_flow** out, const fy_flow_config* cfg, const fy
             if (step < n) dt = c.t_span[step + 1] - t;
         }
         for (int s0 = 0; s0 < n; s0 += 8) TRYC(compute_mod(f, f->t_of_step.data() + s0, std::min(8, n - s0), s0, st));
+    }
+    // The folded LayerNorm-modulate tables (struct comment): W', u, bias' of the qkv and ff1 products for every (Euler step, block).
+    // FY_FLOW_LN_FOLD=0: not built, every LayerNorm-modulate stays its own launch.  Needs the ring kernels' shapes.
+    {
+        const char* ev = getenv("FY_FLOW_LN_FOLD");
+        const bool want = !(ev && atoi(ev) == 0) && D % 128 == 0 && inner % 128 == 0 && FF % 128 == 0 && D % 64 == 0;
+        const size_t n_sb = (size_t)c.n_timesteps * c.depth, QN = (size_t)3 * inner;
+        size_t free_b = 0, total_b = 0;
+        const size_t need = n_sb * (QN + FF) * D * 2 + ((size_t)1 << 30);
+        if (want && hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need) {
+            TRYC(f->pool.alloc(&f->wq_fold, n_sb * QN * D)); TRYC(f->pool.alloc(&f->w1_fold, n_sb * (size_t)FF * D));
+            TRYC(f->pool.alloc(&f->uq_fold, n_sb * QN)); TRYC(f->pool.alloc(&f->bq_fold, n_sb * QN));
+            TRYC(f->pool.alloc(&f->u1_fold, n_sb * (size_t)FF)); TRYC(f->pool.alloc(&f->b1_fold, n_sb * (size_t)FF));
+            for (int sidx = 0; sidx < c.n_timesteps; ++sidx)
+                for (int i = 0; i < c.depth; ++i) {
+                    const float* m = f->mod + ((size_t)sidx * c.depth + i) * 6 * D;       // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+                    const size_t sb = (size_t)sidx * c.depth + i;
+                    const float* ws[3] = {fsrc[i].qw, fsrc[i].kw, fsrc[i].vw};
+                    for (int j = 0; j < 3; ++j)
+                        hipLaunchKernelGGL(fold_row_k, dim3(inner), dim3(256), 0, st, ws[j], f->blk[i].bqkv + (size_t)j * inner, m + D, m,
+                                           f->wq_fold + (sb * QN + (size_t)j * inner) * D, f->uq_fold + sb * QN + (size_t)j * inner, f->bq_fold + sb * QN + (size_t)j * inner, D);
+                    hipLaunchKernelGGL(fold_row_k, dim3(FF), dim3(256), 0, st, fsrc[i].f1w, f->blk[i].b1, m + 4 * D, m + 3 * D,
+                                       f->w1_fold + sb * (size_t)FF * D, f->u1_fold + sb * FF, f->b1_fold + sb * FF, D);
+                }
+            if (hipGetLastError() != hipSuccess) { fy_set_error("fy_flow_create: the fold kernels failed to launch"); return fail(FY_ERR_HIP); }
+            f->fold = true;
+        }
     }
 #undef GETW
 #undef TRYC
@@ -526,10 +589,28 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
     }
     const float* modbase = f->mod + (size_t)slot * c.depth * 6 * D;
     bf16_t* const xn_lo = pr ? f->xn_lo : nullptr;
+    // LayerNorm-modulate folded across the qkv / ff1 products (round 5).  xn = LN(h) (1 + s) + b feeds ONE product each time, and s, b
+    // depend on (Euler step, block) only, so  xn W^T + bias = rstd (h W'^T - mean u) + bias'  with W' = W (1 + s), u = sum_k W',
+    // bias' = bias + W b (made at create).  The product that WRITES h (out-projection, ff2: the gated residual) also leaves bf16(h)
+    // and the rows' partial (sum, sum of squares) per 64-column tile; every workgroup of the consuming product turns the slots of its
+    // own rows into (mean, rstd) while its first operand stage is in flight (as a launch of its own that reduction took 4.4 us - half
+    // of what the fold saves; as the tail of the producer's last workgroup per row panel, behind an agent-scope release, 13 us), reads
+    // bf16(h) against W' and finishes in its epilogue.  That replaces a launch that reads the fp32 stream and writes
+    // the bf16 operand (39.5 MB, 9.3 us at M = 6400, 440 per batch: 8 % of the step's kernel time) by 13 MB more in the producer's
+    // epilogue + ~2 us.  Accuracy: the operand is bf16(h) instead of bf16(normalised h) - the same relative rounding as long as a
+    // row's mean is small against its spread (tests/micro/ln_fold_error_sim.py: estimator error 1.1e-2 against 0.9e-2).
+    // Only on the Euler schedule's own steps (the tables are per step), the default arithmetic and the whole-sequence mask: the
+    // estimator entry (any t), FY_PRECISE and the streaming forms (whose incremental chunks must equal the full pass bit for bit)
+    // keep the separate launch.  The first LayerNorm of a call reads what the position convolution wrote and the last one feeds the
+    // 80-column output projection: those two stay launches as well.
+    const bool fold = f->fold && !pr && !streaming && slot < c.n_timesteps && !(flags & FY_DIRECT) && D % 64 == 0;
+    const size_t sb0 = (size_t)slot * c.depth;
+    auto producer = [&](GemmEpi& e) { e.h_bf16 = f->hb; e.ln_slots = f->ln_slots; };
     for (int i = 0; i < c.depth; ++i) {
         const FlowBlockW& k = f->blk[i];
         const float* m = modbase + (size_t)i * 6 * D;       // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + D, m, f->xn, xn_lo, M, D);
+        const bool fold_q = fold && i > 0;                  // block 0's h comes from the position convolution
+        if (!fold_q) hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + D, m, f->xn, xn_lo, M, D);
         GemmEpi q;
         q.bias = k.bqkv; q.out = f->qkv; q.out_bf16 = 1; q.ldc = 3 * inner;
         // x-transformers rotary embedding (head 0 of q and k only, modules.py:368-373) in the projection's epilogue, on the fp32
@@ -540,20 +621,32 @@ static int dit_forward(fy_flow* f, int nseq, int Tmax, int slot, bool streaming,
             FY_TRY(gemm_split(f->xn, D, k.wqkv, M, 3 * inner, D, q, st));
             FY_TRY(dit_attention_split(f->qkv, f->qkv_lo, f->ao, f->ao_lo, f->seq_len, nseq, Tmax, c.heads, streaming ? c.static_chunk : 0, st));
         } else {
-            FY_TRY(gemm_bf16(f->xn, D, k.wqkv, M, 3 * inner, D, q, st));
+            if (fold_q) {
+                const size_t sb = sb0 + i, QN = (size_t)3 * inner;
+                q.bias = f->bq_fold + sb * QN; q.ln_rows_slots = f->ln_slots; q.ln_dim = D; q.ln_u = f->uq_fold + sb * QN;
+                FY_TRY(gemm_bf16(f->hb, D, f->wq_fold + sb * QN * D, M, 3 * inner, D, q, st));
+            } else FY_TRY(gemm_bf16(f->xn, D, k.wqkv, M, 3 * inner, D, q, st));
             FY_TRY(dit_attention(f->qkv, f->ao, f->seq_len, nseq, Tmax, c.heads, streaming ? c.static_chunk : 0, st));
         }
         GemmEpi o;
         o.mode = EPI_GATE_RESID; o.bias = k.bo; o.resid = f->h; o.gate = m + 2 * D; o.ldc = D;
+        if (fold) producer(o);
         if (pr) { o.a_lo = f->ao_lo; o.w_lo = k.wo_lo; o.gate_ones = f->ones; FY_TRY(gemm_split(f->ao, inner, k.wo, M, D, inner, o, st)); }
         else FY_TRY(gemm_bf16(f->ao, inner, k.wo, M, D, inner, o, st));
-        hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + 4 * D, m + 3 * D, f->xn, xn_lo, M, D);
         GemmEpi g;
         g.bias = k.b1; g.act = ACT_GELU_TANH; g.out = f->ff; g.out_bf16 = 1; g.ldc = FF;
-        if (pr) { g.a_lo = f->xn_lo; g.out_lo = f->ff_lo; g.w_lo = k.w1_lo; FY_TRY(gemm_split(f->xn, D, k.w1, M, FF, D, g, st)); }
-        else FY_TRY(gemm_bf16(f->xn, D, k.w1, M, FF, D, g, st));
+        if (fold) {
+            const size_t sb = sb0 + i;
+            g.bias = f->b1_fold + sb * FF; g.ln_rows_slots = f->ln_slots; g.ln_dim = D; g.ln_u = f->u1_fold + sb * FF;
+            FY_TRY(gemm_bf16(f->hb, D, f->w1_fold + sb * (size_t)FF * D, M, FF, D, g, st));
+        } else {
+            hipLaunchKernelGGL(ln_mod_k, dim3(cdiv(M, 4)), dim3(256), 0, st, f->h, m + 4 * D, m + 3 * D, f->xn, xn_lo, M, D);
+            if (pr) { g.a_lo = f->xn_lo; g.out_lo = f->ff_lo; g.w_lo = k.w1_lo; FY_TRY(gemm_split(f->xn, D, k.w1, M, FF, D, g, st)); }
+            else FY_TRY(gemm_bf16(f->xn, D, k.w1, M, FF, D, g, st));
+        }
         GemmEpi r;
         r.mode = EPI_GATE_RESID; r.bias = k.b2; r.resid = f->h; r.gate = m + 5 * D; r.ldc = D;
+        if (fold && i + 1 < c.depth) producer(r);
         if (pr) { r.a_lo = f->ff_lo; r.w_lo = k.w2_lo; r.gate_ones = f->ones; FY_TRY(gemm_split(f->ff, FF, k.w2, M, D, FF, r, st)); }
         else FY_TRY(gemm_bf16(f->ff, FF, k.w2, M, D, FF, r, st));
     }

@@ -33,6 +33,18 @@ struct GemmEpi {
     // gemm_split only: the lo plane of the WEIGHTS, W_true = W + w_lo with W = bf16(w), w_lo = bf16(w - W), [N][K] like W (general
     // fp32 checkpoints; null = the weights are bf16-representable).  The K loop then runs a second pass over w_lo.
     const bf16_t* w_lo = nullptr;
+    // LayerNorm-modulate folded across a product (flow decoder, default mode; flow.hip says when).  The producer of the residual
+    // stream (EPI_GATE_RESID, ring kernels) also leaves bf16(new resid) in h_bf16 [M][ldc] and, per (row, 64-column tile), the
+    // (sum, sum of squares) of the new values in ln_slots [M][N / 64].  The consumer (EPI_STORE, bf16 output) multiplies bf16(resid)
+    // itself by W' = W (1 + scale) and finishes out = rstd (acc - mean ln_u[n]) + bias[n]; every workgroup first turns the slots of
+    // ITS rows (ln_rows_slots [M][ln_dim / 64], summed in slot order, in double) into (mean, rstd) in LDS - no launch and no
+    // hand-off between workgroups for that (ln_u[n] = sum_k W'[n][k]; `bias` then carries bias + W shift; ln_dim = the row length
+    // the statistics are of = this product's K).
+    bf16_t* h_bf16 = nullptr;
+    float2* ln_slots = nullptr;
+    const float2* ln_rows_slots = nullptr;
+    int ln_dim = 0;
+    const float* ln_u = nullptr;
     const float* gate_ones = nullptr;  // N ones: needed with w_lo only where gemm_split falls back to the register-staged kernel (N % 128 != 0)
     void* out_lo = nullptr;
 #ifdef FY_GEMM_STAMPS

@@ -59,6 +59,31 @@ __device__ __forceinline__ void rope_rotate(float4& v, const float4& t) {
     v.z = cc - ds; v.w = dc + cs;
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), the same value and the same order of additions in every lane: pairs,
+// quads (quad permutes), the two quads of a half (half-row mirror), the two halves (row mirror) - vector-ALU data movement, no trip
+// through the LDS crossbar that __shfl_xor takes (64 of those per 32-row block made the gated-residual epilogue 7 us slower)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));      // quad_perm [1, 0, 3, 2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));      // quad_perm [2, 3, 0, 1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));     // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));     // row_mirror
+    return v;
+}
+
+// The folded LayerNorm-modulate (GemmEpi::ln_rows): out = rstd (acc - mean u) + b, every operation rounded on its own so that all
+// epilogue forms agree bit for bit
+__device__ __forceinline__ float ln_fold1(float acc, float mean, float rstd, float u, float b) {
+#pragma clang fp contract(off)
+    const float t = mean * u;
+    const float d = acc - t;
+    const float y = rstd * d;
+    return y + b;
+}
+__device__ __forceinline__ void ln_fold4(float4& v, const float2& st, const float4& u, const float4& b) {
+    v.x = ln_fold1(v.x, st.x, st.y, u.x, b.x); v.y = ln_fold1(v.y, st.x, st.y, u.y, b.y);
+    v.z = ln_fold1(v.z, st.x, st.y, u.z, b.z); v.w = ln_fold1(v.w, st.x, st.y, u.w, b.w);
+}
+
 // x-transformers apply_rotary_pos_emb on four consecutive output columns starting at n (two interleaved pairs)
 __device__ __forceinline__ void epi_rope(float4& v, const GemmEpi& e, int m, int n) {
     int nn = n >= e.rope_stride ? n - e.rope_stride : n;
@@ -279,6 +304,21 @@ void gemm_set_stamps(unsigned long long* p) { hipMemcpyToSymbol(HIP_SYMBOL(gemm_
 #endif
 #define G2_RING_BYTES (96 * 1024)                            // BN 256: three 32 KB stages; BN 128: three 24 KB stages = 72 KB, so that two workgroups share a CU
 
+// The folded LayerNorm's row statistics (gemm.h): thread r of the workgroup turns the producer's slots of tile row r into (mean, rstd)
+// at smem + ln_off - slots summed in slot order, in double (E[x^2] - mean^2 wants it), eps as the flow decoder's LayerNorm.  Called
+// before the K loop (whose barriers make the values visible to the epilogue); the loads fly under the first stage's.
+__device__ __forceinline__ void ring_ln_rows(char* smem, int ln_off, const GemmEpi& e, int M, int m0, int BM, int tid, int nthreads) {
+    const int n_slots = e.ln_dim >> 6;
+    for (int r = tid; r < BM; r += nthreads) {
+        const float2* sp = e.ln_rows_slots + (long)min(m0 + r, M - 1) * n_slots;
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < n_slots; ++k) { const float2 v = sp[k]; s1 += (double)v.x; s2 += (double)v.y; }
+        const double mean = s1 / e.ln_dim, var = fmax(s2 / e.ln_dim - mean * mean, 0.0);
+        reinterpret_cast<float2*>(smem + ln_off)[r] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-6)));
+    }
+}
+
 // The ring kernels' epilogue (gemm256_k, gemm64_k): from the accumulators - acc (32x32x16 form) or acc4 (16x16x32 form; DE: the
 // transposed products, a lane holds 16 consecutive columns of one row per 16-row tile) - to memory, with the bias, the rotary
 // embedding, GELU, the gated residual or the split planes.  Called by every wave of the workgroup after the K loop.
@@ -286,7 +326,11 @@ void gemm_set_stamps(unsigned long long* p) { hipMemcpyToSymbol(HIP_SYMBOL(gemm_
 // (the one-workgroup-per-CU tilings of 8 waves have the registers for it)
 template <int EPI, int BN, int FM, int MF, bool DE, bool AH>
 __device__ __forceinline__ void ring_epilogue(char* smem, f32x16 (&acc)[(FM + 1) / 2][2], f32x4 (&acc4)[MF ? FM : 1][4], const GemmEpi& e, int M, int N,
-                                              int m0, int n0, int wm, int wn, int wid, int lane) {
+                                              int m0, int n0, int wm, int wn, int wid, int lane, int ln_off = 0) {
+    // (ln_off: where in LDS the caller's ring_ln_rows left the (mean, rstd) of the tile's rows, when e.ln_rows_slots is set)
+    // the thread's coordinates pass through an empty asm: the compiler then cannot compute the epilogue's addresses (bias, table and
+    // residual rows, ...) ABOVE the caller's K loop and carry them through it - in the 128-register kernels it did, and spilled them
+    asm volatile("" : "+v"(lane), "+v"(wm), "+v"(wn), "+v"(wid));
     const int tid = threadIdx.x, lr = lane & 31, kh = lane >> 5;
     (void)tid; (void)lr; (void)kh;
     constexpr int MI = FM / 2;                                      // 32-row blocks (the LDS epilogue walks them: FM even there)
@@ -299,11 +343,13 @@ __device__ __forceinline__ void ring_epilogue(char* smem, f32x16 (&acc)[(FM + 1)
         // Direct epilogue: for 16-row tile i the lane holds row (lane & 15), columns nq .. nq + 15 as acc4[i][j][r] = column 4 j + r.
         // The residual rows (EPI 3) or the rotary table rows (RE) of tile i + 1 are fetched before tile i is stored.
         const int nq = n0 + wn * 64 + (lane >> 4) * 16, mw = m0 + wm * (FM * 16) + (lane & 15);
-        float4 bq[4], gq[EPI == 3 ? 4 : 1];
+        float4 bq[4], gq[EPI == 3 ? 4 : 1], uq[EPI == 0 || EPI == 1 ? 4 : 1];
+        const bool lnf = (EPI == 0 || EPI == 1) && e.ln_rows_slots != nullptr;    // the folded LayerNorm-modulate (gemm.h)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             bq[c] = e.bias ? *reinterpret_cast<const float4*>(e.bias + nq + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (EPI == 3) gq[c] = *reinterpret_cast<const float4*>(e.gate + nq + 4 * c);
+            if (EPI == 0 || EPI == 1) uq[c] = lnf ? *reinterpret_cast<const float4*>(e.ln_u + nq + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         int rope_c = -1;                                            // float2 index of the lane's first pair inside a table row
         if (RE && e.rope) {
@@ -324,6 +370,14 @@ __device__ __forceinline__ void ring_epilogue(char* smem, f32x16 (&acc)[(FM + 1)
                 }
             }
         };
+        // the folded LayerNorm's (mean, rstd) of this lane's FM rows: requested together, ahead of the tile loop
+        float2 lrow[(EPI == 0 || EPI == 1) ? FM : 1];
+        if constexpr (EPI == 0 || EPI == 1) {
+            if (lnf) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) lrow[i] = reinterpret_cast<const float2*>(smem + ln_off)[wm * (FM * 16) + (lane & 15) + i * 16];
+            }
+        }
         if constexpr (PF && AHEAD) fetch(0, cur);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
@@ -332,10 +386,13 @@ __device__ __forceinline__ void ring_epilogue(char* smem, f32x16 (&acc)[(FM + 1)
             const int m = mw + i * 16;
             if (m < M) {
                 uint32_t pk[8], pl[8];
+                float2 lst = make_float2(0.f, 1.f);
+                if constexpr (EPI == 0 || EPI == 1) { if (lnf) lst = lrow[i]; }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float4 v = make_float4(acc4[i][c][0], acc4[i][c][1], acc4[i][c][2], acc4[i][c][3]);
-                    v.x += bq[c].x; v.y += bq[c].y; v.z += bq[c].z; v.w += bq[c].w;
+                    if ((EPI == 0 || EPI == 1) && lnf) ln_fold4(v, lst, uq[c], bq[c]);
+                    else { v.x += bq[c].x; v.y += bq[c].y; v.z += bq[c].z; v.w += bq[c].w; }
                     if constexpr (EPI == 3) {
                         float4 o = cur[c];
                         o.x = fmaf(gq[c].x, v.x, o.x); o.y = fmaf(gq[c].y, v.y, o.y); o.z = fmaf(gq[c].z, v.z, o.z); o.w = fmaf(gq[c].w, v.w, o.w);
@@ -382,9 +439,11 @@ __device__ __forceinline__ void ring_epilogue(char* smem, f32x16 (&acc)[(FM + 1)
     float* park = reinterpret_cast<float*>(smem) + wid * 32 * 68;
     const int c4 = (lane & 15) * 4, rsub = lane >> 4;
     const int n = n0 + wn * 64 + c4;
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gv = bv;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gv = bv, uv = bv;
     if (e.bias) bv = *reinterpret_cast<const float4*>(e.bias + n);
     if (EPI == 3) gv = *reinterpret_cast<const float4*>(e.gate + n);
+    const bool lnf = (EPI == 0 || EPI == 1) && e.ln_rows_slots != nullptr;        // the folded LayerNorm-modulate (gemm.h)
+    if (lnf) uv = *reinterpret_cast<const float4*>(e.ln_u + n);
     // Rotary embedding (EPI 0): only the lanes whose four columns lie in a rotated range fetch (cos, sin) pairs, and they fetch
     // a 32-row block's eight table rows in one batch, one block AHEAD of their use (under the previous block's stores) - fetched
     // where they are used, each row's 16 bytes cost a trip to L2 in the middle of the store loop (qkv at M = 6400: +11 us on the
@@ -447,12 +506,24 @@ __device__ __forceinline__ void ring_epilogue(char* smem, f32x16 (&acc)[(FM + 1)
         for (int it = 0; it < 8; ++it) {
             const int m = mb + it * 4;
             float4 v = vr[it];
-            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            if (lnf) ln_fold4(v, reinterpret_cast<const float2*>(smem + ln_off)[m - m0], uv, bv);
+            else { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
             if (m >= M) continue;
             if (EPI == 3) {
                 float4 o = old[it];
                 o.x = fmaf(gv.x, v.x, o.x); o.y = fmaf(gv.y, v.y, o.y); o.z = fmaf(gv.z, v.z, o.z); o.w = fmaf(gv.w, v.w, o.w);
                 *reinterpret_cast<float4*>(e.resid + (long)m * e.ldc + n) = o;
+                if (e.h_bf16) {
+                    // what the NEXT product reads when LayerNorm-modulate is folded across it (gemm.h): bf16 of the new residual row piece,
+                    // and this wave's 64 columns' (sum, sum of squares) of the row - the 16 lanes of a row meet by shuffles in a fixed order
+                    uint2 hb;
+                    hb.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
+                    hb.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
+                    *reinterpret_cast<uint2*>(e.h_bf16 + (long)m * e.ldc + n) = hb;
+                    float s1 = (o.x + o.y) + (o.z + o.w), s2 = (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                    s1 = row16_sum(s1); s2 = row16_sum(s2);
+                    if ((lane & 15) == 0) e.ln_slots[(long)m * (N >> 6) + ((n0 + wn * 64) >> 6)] = make_float2(s1, s2);
+                }
             } else if (EPI == 2) {
                 *reinterpret_cast<float4*>((float*)e.out + (long)m * e.ldc + n) = v;
             } else if (EPI == 4 || EPI == 5) {
@@ -525,6 +596,8 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
     G2_STAMP(0);
+    constexpr int LN_OFF = 3 * ((SP + 1) * BM + BN) * G2_BK * 2;         // behind the ring (the launcher adds BM x 8 bytes for it)
+    if constexpr (EPI == 0 || EPI == 1) { if (e.ln_rows_slots) ring_ln_rows(smem, LN_OFF, e, M, m0, BM, tid, NWAVE * 64); }
 
     // K steps: K / 32 - or, for the split-operand form with a second weight plane (e.w_lo), twice that: steps [ntk, 2 ntk) walk
     // the same A columns again against the lo plane of W (same rows, same pitch: one pointer difference)
@@ -775,13 +848,13 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mi], fb[ks & 1][ni], acc[mi][ni], 0, 0, 0);
         }
     }
-    ring_epilogue<EPI, BN, 2 * MI, MF, DE, BN == 256>(smem, acc, acc4, e, M, N, m0, n0, wm, wn, wid, lane);
+    ring_epilogue<EPI, BN, 2 * MI, MF, DE, BN == 256>(smem, acc, acc4, e, M, N, m0, n0, wm, wn, wid, lane, LN_OFF);
 }
 
 template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0, int SP = 0>
 static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static std::atomic<bool> attr_set[FY_MAX_DEVICES];       // per device: the attribute belongs to the device's copy of the function
-    const size_t lds = (size_t)3 * ((SP + 1) * BM + BN) * G2_BK * 2;          // 256x256: 96 KB; 320x256: 108 KB (one workgroup per CU); 256x128: 72 KB (two); 128x128: 48 KB (three); split operand: 256x128 120 KB (one), 128x128 72 KB (two)
+    const size_t lds = (size_t)3 * ((SP + 1) * BM + BN) * G2_BK * 2 + ((EPI == 0 || EPI == 1) ? (size_t)BM * 8 : 0);   // (+ the folded LayerNorm's row statistics)  256x256: 96 KB; 320x256: 108 KB (one workgroup per CU); 256x128: 72 KB (two); 128x128: 48 KB (three); split operand: 256x128 120 KB (one), 128x128 72 KB (two)
     const int dev_slot = current_device_slot();
     if (!attr_set[dev_slot].load(std::memory_order_acquire)) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN, BM, STAG, MF, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -841,6 +914,8 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm64_k(const bf16_t* __restrict_
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
     G2_STAMP(0);
+    constexpr int LN_OFF = 2 * STAGE;                                   // behind the two buffers (the launcher adds BM x 8 bytes for it)
+    if constexpr (EPI == 0 || EPI == 1) { if (e.ln_rows_slots) ring_ln_rows(smem, LN_OFF, e, M, m0, BM, tid, NT); }
     // staging: load i of a thread is chunk (tid & 7) of row (tid >> 3) + 128 i of the stage (rows 0 .. BM-1: A, then W).  Sources as a
     // wave-uniform base + one 32-bit byte offset per load (64-bit pointers would not fit the 128 registers), destination offset in LDS
     const char* const Abase = reinterpret_cast<const char*>(A + (long)m0 * lda);
@@ -892,11 +967,12 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm64_k(const bf16_t* __restrict_
         for (int g = 0; g < FM; ++g) {
             if (g + 1 < FM) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(ra[g]));
             else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(ra[g]));
-            if (g + 2 < FM) { if (G64_ABL == 3) ra[g + 2] = f32x4{1.f, 1.f, 1.f, 1.f}; else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra[g + 2]) : "v"(va ^ (xa(g + 2) ^ (uint32_t)(ks * 64))), "n"((g + 2) * 2048)); }
             const frag_ab fa_g = __builtin_bit_cast(frag_ab, ra[g]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { if (G64_ABL == 1) acc4[g][j][0] += rb[j][0] + ra[g][0]; else acc4[g][j] = DE ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(frag_ab, rb[j]), fa_g, acc4[g][j], 0, 0, 0)
                                                                                                            : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_g, __builtin_bit_cast(frag_ab, rb[j]), acc4[g][j], 0, 0, 0); }
+            // (the read two groups ahead goes out BEHIND this group's MFMAs, into the registers fragment g just left: 8 live, not 12)
+            if (g + 2 < FM) { if (G64_ABL == 3) ra[g + 2] = f32x4{1.f, 1.f, 1.f, 1.f}; else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ra[g + 2]) : "v"(va ^ (xa(g + 2) ^ (uint32_t)(ks * 64))), "n"((g + 2) * 2048)); }
             // Staging, one register per MFMA group of the FIRST sub-step (G64_SPREAD): register k holds its 16 bytes of stage t + 1
             // (requested a stage ago) - into the other buffer (last read during stage t - 1, which every wave has left: the barrier),
             // and its load of stage t + 2 goes out at once.  Spread over the groups, the 16 waves' stores and loads do not arrive
@@ -939,14 +1015,19 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm64_k(const bf16_t* __restrict_
 #undef G64_LOAD_STAGE
 #undef G64_STORE_STAGE
     f32x16 acc_unused[(FM + 1) / 2][2];
-    ring_epilogue<EPI, BN, FM, 1, DE, NWAVE == 8>(smem, acc_unused, acc4, e, M, N, m0, n0, wm, wn, wid, lane);
+    // the epilogue gets the thread's coordinates derived AGAIN from the thread id, behind an empty asm: nothing of the epilogue's
+    // address arithmetic can then be live through the K loop (at the 128-register cap every such value was a spill)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wid_e = tid_e >> 6;
+    ring_epilogue<EPI, BN, FM, 1, DE, NWAVE == 8>(smem, acc_unused, acc4, e, M, N, m0, n0, wid_e / WN, wid_e % WN, wid_e, lane_e, LN_OFF);
 }
 
 template <int EPI, int BM, int BN, int NWAVE>
 static int gemm_launch_64(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static PerDeviceOnce attr_once;
     // two buffers: 2 x 64 KB (256x256), 2 x 72 KB (320x256), 2 x 48 KB (256x128) - or what the LDS epilogue parks (a 32 x 64 fp32 tile per wave)
-    const size_t lds = std::max((size_t)2 * (BM + BN) * 128, (EPI == 2 || EPI == 3) ? (size_t)NWAVE * 32 * 68 * 4 : (size_t)0);
+    const size_t lds = std::max((size_t)2 * (BM + BN) * 128 + ((EPI == 0 || EPI == 1) ? (size_t)BM * 8 : 0), (EPI == 2 || EPI == 3) ? (size_t)NWAVE * 32 * 68 * 4 : (size_t)0);
     const int dslot = current_device_slot();
     if (!attr_once.done[dslot].load(std::memory_order_acquire)) {
         HIP_TRY(hipFuncSetAttribute((const void*)gemm64_k<EPI, BM, BN, NWAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1017,7 +1098,9 @@ static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, i
         if constexpr (EPI == 0 || EPI == 1) {
             if ((ov == 6400 || ov == 6408 || ov == 6432 || (ov == 0 && g64)) && N % 256 == 0 && K % 64 == 0) {
                 const int t256 = (N / 256) * cdiv(M, 256);
-                if (ov == 6400 || (ov == 0 && t256 <= cus && 20 * t256 >= 15 * cus)) return gemm_launch_64<EPI, 256, 256, 16>(Ab, lda, W, M, N, K, epi, st);
+                // (the rotary epilogue's 16-wave instantiation does not fit 128 registers without spilling inside the K loop - and a spill of
+                // a register that an inline-asm ds_read is still filling stores garbage - so the rotary products take the 8-wave form)
+                if (ov == 6400 || (ov == 0 && t256 <= cus && 20 * t256 >= 15 * cus)) return gemm_launch_64<EPI, 256, 256, EPI == 1 ? 16 : 8>(Ab, lda, W, M, N, K, epi, st);
                 if (ov == 6408) return gemm_launch_64<EPI, 256, 256, 8>(Ab, lda, W, M, N, K, epi, st);
                 if (ov == 6432 || (ov == 0 && t320 <= cus && 20 * t320 >= 15 * cus)) return gemm_launch_64<EPI, 320, 256, 8>(Ab, lda, W, M, N, K, epi, st);
             }
@@ -1066,6 +1149,12 @@ static int gemm_check(const void* A, int lda, const bf16_t* W, int M, int N, int
 
 int gemm_bf16(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     FY_TRY(gemm_check(A, lda, W, M, N, K, epi, 2));
+    if (epi.h_bf16 || epi.ln_rows_slots) {
+        // the folded LayerNorm-modulate lives in the ring kernels' epilogues only
+        FY_CHECK(N % 128 == 0 && K % G2_BK == 0 && gemm_tile_override != 128 && gemm_tile_override != 64, FY_ERR_ARG, "gemm: the folded LayerNorm needs a ring-kernel shape (N %d, K %d)", N, K);
+        FY_CHECK(!epi.h_bf16 || (epi.mode == EPI_GATE_RESID && epi.ln_slots && ((uintptr_t)epi.h_bf16 & 15) == 0), FY_ERR_ARG, "gemm: h_bf16 goes with the gated residual and ln_slots");
+        FY_CHECK(!epi.ln_rows_slots || (epi.mode == EPI_STORE && epi.out_bf16 && epi.ln_u && !epi.out_lo && epi.ln_dim == K && K % 64 == 0), FY_ERR_ARG, "gemm: ln_rows_slots goes with a bf16 output, ln_u and ln_dim = K");
+    }
     ProfScope prof("gemm_bf16", 2.0 * M * N * K, st);
     return gemm_launch<0>(A, lda, W, M, N, K, epi, st);
 }
