@@ -93,9 +93,9 @@ def run(batch=32, frames=10000, steps=3, warmup=1, flags=0, check=True):
     frames = a.batch * a.frames
     audio = frames * 480 / 24000.0
     # HBM-side traffic: rocprofv3 --pmc cannot sit under a torch process on this pool, so the per-frame figure is the one
-    # measured on the stand-alone driver of the same engine (profiles/r02_hift_pmc.json says how), scaled to this run
+    # measured on the stand-alone driver of the same engine (profiles/r05_hift_pmc.json says how; tests/micro/hift_pmc.py collects it), scaled to this run
     traffic, pmc_name = None, None
-    for pmc_name in ("r03_hift_pmc.json", "r02_hift_pmc.json"):
+    for pmc_name in ("r05_hift_pmc.json", "r04_hift_pmc.json", "r03_hift_pmc.json", "r02_hift_pmc.json"):      # the newest collected
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pmc_name)
         if os.path.exists(pmc) and a.flags == 0:
             traffic = int(json.load(open(pmc))["traffic_bytes_per_frame"] * frames)

@@ -14,6 +14,13 @@
 #pragma once
 #include "common.h"
 
+// the snake every bf16 stream and every LDS staging of the MFMA convs applies (one definition: a stream holds the very values the
+// consumer's staging would have computed)
+__device__ __forceinline__ float snake_fast(float x, float a) {
+    float s = __sinf(x * a);
+    return fmaf(__builtin_amdgcn_rcpf(a + 1e-9f), s * s, x);
+}
+
 struct ConvDesc {
     // input: element (b, row, c) at x + b*x_bs + row*x_ld + c   (fp32)
     const float* x; long x_bs; int x_ld;
@@ -35,9 +42,16 @@ struct ConvDesc {
     //   x_act : the input, ALREADY activated and rounded by its producer, addressed like x (x, pre_act are ignored)
     //   y_act : snake(result; alpha_out) rounded to bf16, addressed like y -- what the consumer conv would have
     //           staged from y; y itself may then be null when nobody else reads it
+    //   y_act2 / y_act3 : further streams of the same result under other alphas (alpha_out2 / alpha_out3) - the three ResBlocks of a
+    //           HiFT stage all start from the up-conv's output, each with its own snake; need y_act
+    //   alpha_mod : the alphas are indexed by (output channel % alpha_mod) when non-zero (the polyphase up-conv's channels are
+    //           [phase][C]: every phase of a channel takes that channel's alpha)
     const bf16_t* x_act;
     bf16_t* y_act;
     const float* alpha_out;
+    bf16_t* y_act2; const float* alpha_out2;
+    bf16_t* y_act3; const float* alpha_out3;
+    int alpha_mod;
 };
 
 // weights of one conv in both kernel layouts (either may be null)

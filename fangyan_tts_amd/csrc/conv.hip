@@ -34,10 +34,6 @@ __device__ __forceinline__ float apply_pre(float v, int act, float slope, float 
     if (act == ACT_SNAKE) return act_snake(v, alpha);
     return v;
 }
-__device__ __forceinline__ float snake_fast(float x, float a) {
-    float s = __sinf(x * a);
-    return fmaf(__builtin_amdgcn_rcpf(a + 1e-9f), s * s, x);
-}
 __device__ __forceinline__ float apply_post(float v, int act, float slope) {
     if (act == ACT_ELU) return act_elu(v);
     if (act == ACT_LEAKY) return act_leaky(v, slope);
@@ -388,7 +384,13 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
     const int co = g * Cout_g + n32_base * 32 + (col_live ? c4 : 0);
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), av = make_float4(1.f, 1.f, 1.f, 1.f);
     if (d.bias) bv = *reinterpret_cast<const float4*>(d.bias + co);
-    if (ya) av = *reinterpret_cast<const float4*>(d.alpha_out + co);
+    const int ca = d.alpha_mod ? co % d.alpha_mod : co;        // (a float4 of channels never straddles a phase: alpha_mod % 32 == 0)
+    if (ya) av = *reinterpret_cast<const float4*>(d.alpha_out + ca);
+    bf16_t* ya2 = ya && d.y_act2 ? d.y_act2 + (long)b * d.y_bs : nullptr;
+    bf16_t* ya3 = ya && d.y_act3 ? d.y_act3 + (long)b * d.y_bs : nullptr;
+    float4 av2 = av, av3 = av;
+    if (ya2) av2 = *reinterpret_cast<const float4*>(d.alpha_out2 + ca);
+    if (ya3) av3 = *reinterpret_cast<const float4*>(d.alpha_out3 + ca);
     // three instantiations: the plain one (no output activation, no reflect pad: every ResBlock conv) and the Mish one stay small --
     // the generic one carries the transcendental code of every activation kind at each of its 64 elements
     auto epilogue = [&](auto kind_tag) {
@@ -439,11 +441,16 @@ __global__ __launch_bounds__(WAVES_P* WAVES_C * 64) void conv1d_bf16_mfma_k(Conv
                 o.z = fmaf(v.z + rv[it].z, osc, ov[it].z); o.w = fmaf(v.w + rv[it].w, osc, ov[it].w);
                 if (yb) *reinterpret_cast<float4*>(yb + (long)(p + qoff) * d.y_ld + co) = o;
                 if (ya) {                                        // what the consumer conv would stage from this value
-                    o.x = snake_fast(o.x, av.x); o.y = snake_fast(o.y, av.y); o.z = snake_fast(o.z, av.z); o.w = snake_fast(o.w, av.w);
-                    uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
-                    *reinterpret_cast<uint2*>(ya + (long)(p + qoff) * d.y_ld + co) = pk;
+                    auto put = [&](bf16_t* dst, const float4& a) {
+                        const float s0 = snake_fast(o.x, a.x), s1 = snake_fast(o.y, a.y), s2 = snake_fast(o.z, a.z), s3 = snake_fast(o.w, a.w);
+                        uint2 pk;
+                        pk.x = (uint32_t)f32_to_bf16(s0) | ((uint32_t)f32_to_bf16(s1) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(s2) | ((uint32_t)f32_to_bf16(s3) << 16);
+                        *reinterpret_cast<uint2*>(dst + (long)(p + qoff) * d.y_ld + co) = pk;
+                    };
+                    put(ya, av);
+                    if (ya2) put(ya2, av2);
+                    if (ya3) put(ya3, av3);
                 }
                 if (GENERIC && mi == 0 && it == 0 && d.reflect1 && p == 1) {                      // ReflectionPad1d((1,0)): row 0 mirrors conv row 1
                     float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), o0 = r0;
@@ -510,6 +517,8 @@ int conv1d_bf16_mfma(const ConvDesc& d, const ConvW& w, bool precise, hipStream_
     FY_CHECK(!d.y || ((uintptr_t)d.y & 15) == 0, FY_ERR_ARG, "conv1d_bf16_mfma: output must be 16-B aligned");
     FY_CHECK(!d.y_act || (((uintptr_t)d.y_act & 7) == 0 && d.alpha_out && !d.reflect1), FY_ERR_ARG,
              "conv1d_bf16_mfma: the bf16 output stream needs 8-B alignment, alpha_out and no reflect pad");
+    FY_CHECK((!d.y_act2 || (d.y_act && d.alpha_out2 && ((uintptr_t)d.y_act2 & 7) == 0)) && (!d.y_act3 || (d.y_act && d.alpha_out3 && ((uintptr_t)d.y_act3 & 7) == 0)) &&
+             d.alpha_mod % 32 == 0, FY_ERR_ARG, "conv1d_bf16_mfma: further output streams need the first one, their alphas and 8-B alignment; alpha_mod %% 32 == 0");
     FY_CHECK(d.y || !(d.accumulate || d.reflect1), FY_ERR_ARG, "conv1d_bf16_mfma: accumulate / reflect need the fp32 output");
     FY_CHECK(!d.add_resid || (((uintptr_t)d.resid & 15) == 0 && (d.r_bs % 4) == 0 && d.r_ld % 4 == 0), FY_ERR_ARG,
              "conv1d_bf16_mfma: residual must be 16-B aligned");

@@ -31,6 +31,9 @@ struct fy_hift {
     // activations (channels-last)
     float *mel_cl, *f0a, *f0b, *f0, *rad_phase, *source, *s_stft, *x_pre, *post, *spec;
     float *xs[N_UP], *x[N_UP], *r[N_UP], *xt[N_UP], *si[N_UP];
+    // three bf16 streams per stage: the up-conv's output under the first snake of each of the stage's ResBlocks, written by the up-conv's
+    // epilogue (and slot 0, earlier in the stage, the source down-sampler's output under the source ResBlock's first snake)
+    bf16_t* sa[N_UP] = {nullptr, nullptr, nullptr};
     // bf16 'super-row' copies of s_stft for the strided source down-samplers (see stft16_k); null when not built
     bf16_t* sb[N_UP] = {nullptr, nullptr, nullptr};
     int sb_ld[N_UP] = {0, 0, 0};
@@ -204,6 +207,9 @@ extern "C" int fy_hift_create(fy_hift** out, const fy_hift_config* cfg, const fy
         TRYC(h->pool.alloc(&h->r[i], n));
         TRYC(h->pool.alloc(&h->xt[i], n));
         TRYC(h->pool.alloc(&h->si[i], n));
+        float* sa = nullptr;
+        TRYC(h->pool.alloc(&sa, (N_RB * n + 1) / 2));
+        h->sa[i] = reinterpret_cast<bf16_t*>(sa);
     }
     for (int i = 0; i < N_UP; ++i)
         if (h->sb_ld[i]) TRYC(h->pool.alloc(&h->sb[i], B * ((size_t)h->L(i, (int)F) + 1) * h->sb_ld[i]));
@@ -484,8 +490,11 @@ static int hift_source(fy_hift* h, const float* f0, int B, int Fmax, const float
 // producer's epilogue already activated (snake with the consumer's alpha) and rounded -- the very values the
 // consumer's LDS staging would have computed from the fp32 tensor -- so `xt` holds two bf16 streams instead of one
 // fp32 tensor: snake2_j(conv1_j(.)) for conv2_j, and snake1_{j+1}(x) for conv1_{j+1}.
+// x_act0: x_in under snake(.; rb.a1[0]) as a bf16 stream when x_in's producer wrote one (the default path: iteration 0 then stages
+// a copy like every other iteration instead of activating fp32 rows, halo included); null: iteration 0 activates x_in itself.
 static int run_resblock(fy_hift* h, const HiftConvs::RB& rb, const float* x_in, float* work, float* xt, float* final_dst,
-                        float final_scale, int final_acc, int B, int Lmax, const int* len, int C, uint32_t flags, hipStream_t st) {
+                        float final_scale, int final_acc, int B, int Lmax, const int* len, int C, uint32_t flags, hipStream_t st,
+                        const bf16_t* x_act0 = nullptr) {
     const fy_hift_config& c = h->cfg;
     const long bs = (long)Lmax * C;
     const bool streams = !(flags & (FY_DIRECT | FY_PRECISE)) && rb.c1[0].w_mfma && C % 32 == 0;
@@ -499,11 +508,11 @@ static int run_resblock(fy_hift* h, const HiftConvs::RB& rb, const float* x_in, 
         // rows, so the input of an iteration is never the buffer it writes: the bf16 streams alternate between the two slots of
         // `xt`; the fp32 input of iteration 0 (read with a halo) goes to `work`, or to final_dst when x_in IS work.
         const float* cur = x_in;
-        bf16_t* sin = nullptr;
+        const bf16_t* sin = x_act0;
         for (int j = 0; j < N_DIL; ++j) {
             const bool last = j == N_DIL - 1;
             ResIterDesc r{};
-            r.x = j == 0 ? x_in : nullptr; r.x_act = sin; r.resid = cur; r.bs = bs; r.ld = C;
+            r.x = sin ? nullptr : x_in; r.x_act = sin; r.resid = cur; r.bs = bs; r.ld = C;
             r.alpha1 = rb.a1[j]; r.alpha2 = rb.a2[j]; r.bias1 = rb.c1[j].bias; r.bias2 = rb.c2[j].bias;
             r.KW = rb.c1[j].KW; r.dil = c.rb_d[j];
             r.B = B; r.L = Lmax; r.C = C; r.len = len;
@@ -527,6 +536,7 @@ static int run_resblock(fy_hift* h, const HiftConvs::RB& rb, const float* x_in, 
         d.pre_act = ACT_SNAKE; d.alpha = rb.a1[j]; d.bias = rb.c1[j].bias;
         if (streams) {
             if (j > 0) d.x_act = a1;
+            else if (x_act0) d.x_act = x_act0;
             d.y = nullptr; d.y_act = a2; d.alpha_out = rb.a2[j];
         }
         FY_TRY(run_conv(d, rb.c1[j], flags, st));
@@ -550,12 +560,18 @@ static int run_resblock(fy_hift* h, const HiftConvs::RB& rb, const float* x_in, 
 }
 
 // ReflectionPad1d((1,0)) after the polyphase up-conv wrote rows 1..: row 0 = conv row 1 + si[0] = y[2] - si[2] + si[0]
-__global__ void reflect_row0_k(float* __restrict__ y, const float* __restrict__ si, long bs, int C) {
+// ya[k] (optional): row 0 of the up-conv's bf16 streams, snake(row 0; al[k]) as the conv's epilogue writes the other rows
+struct Row0Streams { bf16_t* ya[N_RB]; const float* al[N_RB]; };
+__global__ void reflect_row0_k(float* __restrict__ y, const float* __restrict__ si, long bs, int C, Row0Streams rs) {
     int b = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float* yb = y + (long)b * bs;
     const float* sb = si + (long)b * bs;
-    yb[c] = yb[2 * C + c] - sb[2 * C + c] + sb[c];
+    const float v = yb[2 * C + c] - sb[2 * C + c] + sb[c];
+    yb[c] = v;
+#pragma unroll
+    for (int k = 0; k < N_RB; ++k)
+        if (rs.ya[k]) rs.ya[k][(long)b * bs + c] = f32_to_bf16(snake_fast(v, rs.al[k][c]));
 }
 
 static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, hipStream_t st) {
@@ -564,6 +580,9 @@ static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, 
     const int spf = h->stft_per_frame, up = h->up_total;
     const int Tmax = Fmax * spf + 1;
     const bool streams = !(flags & (FY_DIRECT | FY_PRECISE));
+    // FY_HIFT_ACT0=0: the first iteration of every ResBlock activates its fp32 input itself (rounds 1-4), for A/B runs
+    static const bool act0_on = !(getenv("FY_HIFT_ACT0") && atoi(getenv("FY_HIFT_ACT0")) == 0);
+    const bool act0 = streams && act0_on;
     SuperRows sr;
     for (int i = 0; i < N_UP; ++i) {
         int k, s;
@@ -591,6 +610,7 @@ static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, 
         {   // source branch: si = source_resblocks[i](source_downs[i](s_stft)), generator.py:690-691
             int k, s;
             source_down_shape(c, i, &k, &s);
+            const bf16_t* src_act = nullptr;
             ConvDesc d = base_desc(B);
             d.x = h->s_stft; d.x_bs = (long)Tmax * 18; d.x_ld = 18; d.L_in = Tmax; d.in_len = h->lens + 4 * mb;
             d.y = h->r[i]; d.y_bs = bs; d.y_ld = C; d.L_out = Lmax; d.out_len = len;
@@ -598,12 +618,14 @@ static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, 
             if (sr.p[i]) {       // stride-1 form over the bf16 super-rows (super_pack_k)
                 d.x_act = sr.p[i]; d.x_bs = sr.bs[i]; d.x_ld = sr.ld[i]; d.L_in = Lmax + 1; d.in_len = nullptr;
                 d.Cin = sr.ld[i]; d.KW = s == 1 ? 1 : 2; d.stride = 1; d.pad_left = 0;
+                if (act0 && C % 32 == 0) { d.y_act = h->sa[i]; d.alpha_out = h->w.src_rb[i].a1[0]; src_act = h->sa[i]; }
                 FY_TRY(conv1d_bf16_mfma(d, h->sd_mfma[i], false, st));
             } else {
                 FY_TRY(conv1d_f32_direct(d, h->w.source_downs[i], st));
             }
-            FY_TRY(run_resblock(h, h->w.src_rb[i], h->r[i], h->r[i], h->xt[i], h->si[i], 1.f, 0, B, Lmax, len, C, flags, st));
+            FY_TRY(run_resblock(h, h->w.src_rb[i], h->r[i], h->r[i], h->xt[i], h->si[i], 1.f, 0, B, Lmax, len, C, flags, st, src_act));
         }
+        const bf16_t* x_act[N_RB] = {nullptr, nullptr, nullptr};
         {   // x = ups[i](leaky_relu(x)) [reflect pad on the last stage] + si, generator.py:683-692
             ConvDesc d = base_desc(B);
             d.x = xin; d.x_bs = (long)Lin_max * Cin; d.x_ld = Cin; d.L_in = Lin_max; d.in_len = len_in;
@@ -618,9 +640,19 @@ static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, 
                 d.up = 1; d.KW = h->ups_poly[i].KW; d.pad_left = d.KW - 1; d.Cout = C * u; d.bias = h->ups_poly[i].bias;
                 d.L_out = Lin_max; d.out_len = len_in;
                 d.y = h->x[i] + off; d.y_ld = C * u; d.resid = h->si[i] + off; d.r_ld = C * u; d.reflect1 = 0;
+                Row0Streams rs{};
+                if (act0 && C % 32 == 0) {
+                    // the stage's three ResBlocks all start from this output: one stream each, under their own first snake
+                    const size_t n = (size_t)B * bs;
+                    for (int j = 0; j < N_RB; ++j) { x_act[j] = h->sa[i] + j * n; rs.ya[j] = h->sa[i] + j * n; rs.al[j] = h->w.rb[i * N_RB + j].a1[0]; }
+                    d.y_act = h->sa[i] + off; d.alpha_out = rs.al[0];
+                    d.y_act2 = h->sa[i] + n + off; d.alpha_out2 = rs.al[1];
+                    d.y_act3 = h->sa[i] + 2 * n + off; d.alpha_out3 = rs.al[2];
+                    d.alpha_mod = C;
+                }
                 FY_TRY(conv1d_bf16_mfma(d, h->ups_poly[i], false, st));
                 if (off) {
-                    hipLaunchKernelGGL(reflect_row0_k, dim3(cdiv(C, 256), B), dim3(256), 0, st, h->x[i], h->si[i], bs, C);
+                    hipLaunchKernelGGL(reflect_row0_k, dim3(cdiv(C, 256), B), dim3(256), 0, st, h->x[i], h->si[i], bs, C, rs);
                     HIP_TRY(hipGetLastError());
                 }
             } else {
@@ -628,7 +660,7 @@ static int hift_decode(fy_hift* h, int B, int Fmax, float* wav, uint32_t flags, 
             }
         }
         for (int j = 0; j < N_RB; ++j)   // x = mean_j resblocks[3i+j](x), generator.py:694-700
-            FY_TRY(run_resblock(h, h->w.rb[i * N_RB + j], h->x[i], h->r[i], h->xt[i], h->xs[i], 1.f / N_RB, j > 0, B, Lmax, len, C, flags, st));
+            FY_TRY(run_resblock(h, h->w.rb[i * N_RB + j], h->x[i], h->r[i], h->xt[i], h->xs[i], 1.f / N_RB, j > 0, B, Lmax, len, C, flags, st, x_act[j]));
         xin = h->xs[i]; Cin = C; Lin_max = Lmax; len_in = len;
     }
     {   // conv_post on leaky_relu(x, 0.01), generator.py:702-703

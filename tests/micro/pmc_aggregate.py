@@ -13,6 +13,9 @@ import sys
 from collections import defaultdict
 
 
+FAMILIES = {"dit_linears": ("gemm256_k", "gemm64_k")}      # every launch bench.py's "gemm_bf16" events bracket
+
+
 def short(name):
     name = re.sub(r"\(.*", "", name)
     name = re.sub(r"^void ", "", name)
@@ -41,6 +44,16 @@ def main():
         n = max(fn, wn, 1)
         out["kernels"][k] = {"launches": n, "read_bytes": round(2 * fb / max(fn, 1)), "write_bytes": round(wb / max(wn, 1)),
                              "traffic_bytes": round(2 * fb / max(fn, 1) + wb / max(wn, 1))}
+    # kernel families a roofline entry is quoted on: the launch-weighted mean over their members (bench.py reads families.dit_linears)
+    out["families"] = {}
+    for fam, members in FAMILIES.items():
+        ks = [out["kernels"][m] for m in members if m in out["kernels"]]
+        n = sum(k["launches"] for k in ks)
+        if n:
+            out["families"][fam] = {"members": [m for m in members if m in out["kernels"]], "launches": n,
+                                    "read_bytes": round(sum(k["read_bytes"] * k["launches"] for k in ks) / n),
+                                    "write_bytes": round(sum(k["write_bytes"] * k["launches"] for k in ks) / n),
+                                    "traffic_bytes": round(sum(k["traffic_bytes"] * k["launches"] for k in ks) / n)}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     for k, v in list(out["kernels"].items())[:12]:
         print(f"{k[:50]:50s} {v['launches']:6d} launches  read {v['read_bytes'] / 1e6:10.2f} MB  write {v['write_bytes'] / 1e6:9.2f} MB")

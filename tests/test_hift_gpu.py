@@ -183,8 +183,10 @@ rb = [eng.resblock(i, torch.from_numpy(synth.normal(f"in.hift.rb.{{i // 3}}.{{i 
 np.savez({str(tmp_path / 'out.npz')!r}, wav=wav.cpu().numpy(), **{{f"rb{{k}}": v for k, v in enumerate(rb)}})
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # the two-launch form, and the fused form extended to the 256-channel stage (off by default: it measured slower)
-    for extra in ({"FY_HIFT_FUSE": "0"}, {"FY_HIFT_FUSE256": "1"}):
+    # the two-launch form, the fused form extended to the 256-channel stage (off by default: it measured slower), and rounds 1-4's
+    # first iterations (FY_HIFT_ACT0=0: each ResBlock activates the fp32 up-conv / source output itself instead of copying the bf16
+    # stream the producer's epilogue wrote under that ResBlock's first snake - the same values by construction)
+    for extra in ({"FY_HIFT_FUSE": "0"}, {"FY_HIFT_FUSE256": "1"}, {"FY_HIFT_ACT0": "0"}, {"FY_HIFT_ACT0": "0", "FY_HIFT_FUSE": "0"}):
         envv = dict(os.environ, PYTHONPATH=os.pathsep.join([root] + sys.path), **extra)
         r = subprocess.run([sys.executable, "-c", script], env=envv, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
