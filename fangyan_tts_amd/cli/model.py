@@ -7,6 +7,7 @@ All three stages run in libfy_cosy3 (HIP); this file only moves pointers around.
 """
 from __future__ import annotations
 
+import os
 import threading
 from typing import Dict, Iterable, List, Optional, Sequence
 
@@ -26,6 +27,49 @@ class _Lane:
         self.uniforms = None
 
 
+class _LmAhead:
+    """The LM of one stream=True generation on a host thread and HIP stream of its own (cli/model.py:104-129 llm_job): steps the lane's
+    LM handle in slices until the generation ends and publishes (tokens kept, done) after each."""
+    SLICE = 8                                               # fy_llm_step reads the stop flags every 8 steps anyway
+
+    def __init__(self, model, ln, n0: int, first_need: int):
+        import threading
+        self.n, self.done, self.err, self._stop = n0, False, None, False
+        self.cv = threading.Condition()
+        if getattr(ln, "lm_stream", None) is None:
+            ln.lm_stream = torch.cuda.Stream(device=model.device)
+        dev, st = model.device, ln.lm_stream
+        st.wait_stream(ln.stream if ln.stream is not None else torch.cuda.current_stream(dev))   # (begin has completed: it returned the first count)
+
+        def job():
+            try:
+                with torch.inference_mode(), torch.cuda.device(dev), torch.cuda.stream(st):
+                    n, done, k = self.n, False, max(1, first_need - n0)
+                    while not done and not self._stop:
+                        (n,), (done,) = ln.llm.step(k)
+                        with self.cv:
+                            self.n, self.done = n, done
+                            self.cv.notify_all()
+                        k = self.SLICE
+            except BaseException as e:                      # surfaces in the consumer's thread
+                with self.cv:
+                    self.err, self.done = e, True
+                    self.cv.notify_all()
+        self.th = threading.Thread(target=job, name="fy-lm-ahead", daemon=True)
+        self.th.start()
+
+    def wait_for(self, need: int):
+        with self.cv:
+            self.cv.wait_for(lambda: self.n >= need or self.done)
+            if self.err is not None:
+                raise self.err
+            return self.n, self.done
+
+    def stop(self):
+        self._stop = True
+        self.th.join()
+
+
 class CosyVoice3Model:
     def __init__(self, llm_weights: Dict[str, torch.Tensor], flow_weights: Dict[str, torch.Tensor],
                  hift_weights: Dict[str, torch.Tensor], cfg: ModelCfg = ModelCfg(), device: Optional[torch.device] = None,
@@ -33,7 +77,8 @@ class CosyVoice3Model:
                  rand_noise: Optional[torch.Tensor] = None, rand_ini: Optional[torch.Tensor] = None,
                  sine_noise: Optional[torch.Tensor] = None, fp16: bool = False, keep_llm_weights: bool = False, n_llm: int = 1,
                  sampler: str = "greedy", sampler_seed: int = 1986, lm_group: int = 1, concurrency: int = 1, flow_workers: int = 1,
-                 flow_group: int = 1, cache_prompts: bool = True, incremental_stream: bool = True, llm_weight_planes: int = 0):
+                 flow_group: int = 1, cache_prompts: bool = True, incremental_stream: bool = True, llm_weight_planes: int = 0,
+                 stream_lm_ahead: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError("fangyan_tts_amd needs an AMD GPU (ROCm); there is no CPU path")
         self.device = device or torch.device("cuda", torch.cuda.current_device())
@@ -49,6 +94,9 @@ class CosyVoice3Model:
         # reference's schedule ends every chunk on a mask boundary; the reference itself (and False here) re-runs the flow decoder
         # over everything so far for every chunk (cli/model.py:339-369).  The last call (no mask) is always a full pass.
         self.incremental_stream = bool(incremental_stream)
+        # stream=True: the LM keeps generating on a stream and host thread of its own while the chunks are decoded (the reference's
+        # llm_job thread, cli/model.py:104-129, 339-358); False: the LM is stepped on demand between two chunks, on the chunk's stream.
+        self.stream_lm_ahead = bool(stream_lm_ahead) and os.environ.get("FY_STREAM_LM_AHEAD", "1") != "0"
         self.max_batch, self.max_tokens, self.max_prompt_tokens = max_batch, max_tokens, max_prompt_tokens
         max_frames = 2 * (max_tokens + max_prompt_tokens)
         # n_llm > 1: extra LM handles (own KV cache and workspace) so tts_pipeline can decode several batches at once;
@@ -634,6 +682,7 @@ class CosyVoice3Model:
         # current stream only INSIDE the engine calls: the consumer's own torch work between two chunks stays on the
         # consumer's stream.  An abandoned generator releases the lane when it is closed or collected (GeneratorExit).
         ln = self._acquire_lane()
+        ahead, mode_was = None, None
         try:
             with self._lane_stream(ln):
                 if source_tokens is None:
@@ -646,6 +695,14 @@ class CosyVoice3Model:
             pad = -(-n_fp // hop0) * hop0 - n_fp
             offset, speech_offset, mel_all = 0, 0, None
             ln.flow.stream_reset()                          # the incremental flow calls of this stream start from nothing
+            # The LM runs ahead of the chunks on its own stream and thread (the reference's llm_job): it publishes (tokens kept, done)
+            # after every slice of steps - a slice ends with the ids complete in memory (fy_llm_step waits for its stream), so the
+            # chunk's stream may read out[:, :n] without an event.  The first slice is what the first chunk lacks.
+            if source_tokens is None and self.stream_lm_ahead and not done:
+                if os.environ.get("FY_STREAM_LM_MODE"):    # A/B: the LM's decode form beside the chunks (0 per-operation, 1, 2 few-CU)
+                    mode_was = ln.llm.decode_mode
+                    ln.llm.set_decode_mode(int(os.environ["FY_STREAM_LM_MODE"]))
+                ahead = _LmAhead(self, ln, n, offset + hop0 + pad + look)
 
             def token2wav(n_in, offset, mel_all, speech_offset, streaming, finalize):
                 mel = ln.flow.inference(out[:, :n_in], [n_in], ptok, [n_fp], pfeat, [n_pf], emb, self.rand_noise,
@@ -660,6 +717,8 @@ class CosyVoice3Model:
 
             while True:
                 need = offset + (hop0 + pad if offset == 0 else hop0) + look
+                if ahead is not None:
+                    n, done = ahead.wait_for(need)
                 with self._lane_stream(ln):
                     while n < need and not done:            # the silent-token filter may drop tokens: ask again until enough
                         (n,), (done,) = ln.llm.step(need - n)
@@ -675,6 +734,10 @@ class CosyVoice3Model:
             self.last_mel, self.last_frames = mel_all, [mel_all.shape[2]]
             yield {"tts_speech": wav}
         finally:
+            if ahead is not None:
+                ahead.stop()                                # (an abandoned generator: the LM thread ends after its current slice)
+                if mode_was is not None:
+                    ln.llm.set_decode_mode(mode_was)
             self._release_lane(ln)
 
     # ------------------------------------------------------------------ reference-shaped path

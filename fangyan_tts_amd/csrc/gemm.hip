@@ -570,7 +570,11 @@ __device__ __forceinline__ void ring_epilogue(char* smem, f32x16 (&acc)[(FM + 1)
 // on it (MI355X_MICROARCH.md, DVFS give-back item 7): 5-19 % less time at two or more workgroups per CU.
 // SP = 1: the split-operand form (gemm_split): the stage holds TWO A tiles, the hi and the lo plane of x = hi + lo, and every
 // fragment pair meets its B fragment in two MFMAs that accumulate into the same registers (MF = 1 only).
-template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0, int SP = 0>
+// NST: stages of the ring.  3 at the sizes above (two or three workgroups per CU hide each other's waits).  A launch with fewer tiles
+// than CUs (stream=True chunks: a hundred to a few hundred rows) is bound by memory latency x the bytes ONE workgroup keeps in flight
+// (two 16 KB stages: 512 KB of operands in ~15 us); NST = 8 keeps seven stages in flight in the LDS nobody else on the CU wants.
+// Same K order, same bits.
+template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0, int SP = 0, int NST = 3>
 __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ W, int M, int N, int K, GemmEpi e) {
     extern __shared__ __attribute__((aligned(16))) bf16_t gm_smem[];
     char* smem = reinterpret_cast<char*>(gm_smem);
@@ -586,7 +590,8 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     // Its B fragment reads 4 rows out of every 16, so rows 16 apart must sit in different slots: the swizzle gets a (row >> 4) term.
     constexpr bool DE = MF && G2_DIRECT && EPI != 2 && EPI != 3;      // fp32 outputs (64-byte runs per row from here) stay on the LDS epilogue's full lines: out-proj 24 -> 32 us with this one
     auto SW = [](int row) -> int { return DE ? (G2_SW(row) ^ ((0 - (row >> 4)) & 3)) : G2_SW(row); };
-    constexpr int STAGE = (APL * BM + BN) * G2_BK * 2, STAGES = 3, NB = BN / (NWAVE * 16);   // NB: B DMAs per wave and stage
+    constexpr int STAGE = (APL * BM + BN) * G2_BK * 2, STAGES = NST, NB = BN / (NWAVE * 16);   // NB: B DMAs per wave and stage
+    static_assert(NST == 3 || (!STAG && !(MF && G2_INTERLEAVE) && NST <= 9), "deeper rings: the plain loop only");
     constexpr int NA_ALL = APL * BM / 16, NA = (NA_ALL + NWAVE - 1) / NWAVE, NA_LAST = NA_ALL - (NA - 1) * NWAVE;   // A DMAs: wave-instruction j = i * NWAVE + wid fills rows [16 j, 16 j + 16) (SP: of plane j / (BM / 16)); the last round only on waves < NA_LAST
     constexpr int BOFF = APL * BM * G2_BK * 2;                            // the B tile follows the A tile(s) inside a stage
     const int wm = wid / WN, wn = wid % WN, lr = lane & 31, kh = lane >> 5;
@@ -596,7 +601,7 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
     G2_STAMP(0);
-    constexpr int LN_OFF = 3 * ((SP + 1) * BM + BN) * G2_BK * 2;         // behind the ring (the launcher adds BM x 8 bytes for it)
+    constexpr int LN_OFF = NST * ((SP + 1) * BM + BN) * G2_BK * 2;       // behind the ring (the launcher adds BM x 8 bytes for it)
     if constexpr (EPI == 0 || EPI == 1) { if (e.ln_rows_slots) ring_ln_rows(smem, LN_OFF, e, M, m0, BM, tid, NWAVE * 64); }
 
     // K steps: K / 32 - or, for the split-operand form with a second weight plane (e.w_lo), twice that: steps [ntk, 2 ntk) walk
@@ -785,9 +790,26 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
         // stage t has landed once at most the stages issued after it are still outstanding (2 + NB DMAs per stage per wave)
         const int ahead = min(nt - 1 - t, STAGES - 2);
         constexpr int D = NA + NB;                                       // DMAs per stage of a wave that takes part in every round (2 D <= 15: the count fits the low four bits)
+        if constexpr (NST == 3) {
         if (ahead == 0) __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
         else if (a_last) { if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * D)); else __builtin_amdgcn_s_waitcnt(0x0F70 | D); }
         else { if (ahead >= 2) __builtin_amdgcn_s_waitcnt(0x0F70 | (2 * (D - 1))); else __builtin_amdgcn_s_waitcnt(0x0F70 | (D - 1)); }
+        } else {
+            // vmcnt(ahead x the wave's DMAs per stage): six bits, the high two in bits 15:14 of the immediate
+            static_assert(NA_LAST == NWAVE && (NST - 2) * D <= 63, "every wave issues D DMAs per stage; the count fits vmcnt");
+#define G2_VM(n) (0x0F70 | ((n) & 15) | (((n) >> 4) << 14))
+            switch (ahead) {
+                case 0: __builtin_amdgcn_s_waitcnt(G2_VM(0)); break;
+                case 1: __builtin_amdgcn_s_waitcnt(G2_VM(1 * D)); break;
+                case 2: __builtin_amdgcn_s_waitcnt(G2_VM(2 * D)); break;
+                case 3: __builtin_amdgcn_s_waitcnt(G2_VM(3 * D)); break;
+                case 4: __builtin_amdgcn_s_waitcnt(G2_VM(4 * D)); break;
+                case 5: __builtin_amdgcn_s_waitcnt(G2_VM(5 * D)); break;
+                case 6: __builtin_amdgcn_s_waitcnt(G2_VM(6 * D)); break;
+                default: __builtin_amdgcn_s_waitcnt(G2_VM(7 * D)); break;
+            }
+#undef G2_VM
+        }
         __builtin_amdgcn_s_barrier();                               // everyone's part of stage t is in LDS; the slot of stage t-1 is free
         if (t == 0) G2_STAMP(1);
         const bool refill = t + STAGES - 1 < nt;
@@ -851,17 +873,17 @@ __global__ __launch_bounds__(512) void gemm256_k(const bf16_t* __restrict__ A, i
     ring_epilogue<EPI, BN, 2 * MI, MF, DE, BN == 256>(smem, acc, acc4, e, M, N, m0, n0, wm, wn, wid, lane, LN_OFF);
 }
 
-template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0, int SP = 0>
+template <int EPI, int BN, int BM = 256, int STAG = 0, int MF = 0, int SP = 0, int NST = 3>
 static int gemm_launch_256(const bf16_t* A, int lda, const bf16_t* W, int M, int N, int K, const GemmEpi& epi, hipStream_t st) {
     static std::atomic<bool> attr_set[FY_MAX_DEVICES];       // per device: the attribute belongs to the device's copy of the function
-    const size_t lds = (size_t)3 * ((SP + 1) * BM + BN) * G2_BK * 2 + ((EPI == 0 || EPI == 1) ? (size_t)BM * 8 : 0);   // (+ the folded LayerNorm's row statistics)  256x256: 96 KB; 320x256: 108 KB (one workgroup per CU); 256x128: 72 KB (two); 128x128: 48 KB (three); split operand: 256x128 120 KB (one), 128x128 72 KB (two)
+    const size_t lds = (size_t)NST * ((SP + 1) * BM + BN) * G2_BK * 2 + ((EPI == 0 || EPI == 1) ? (size_t)BM * 8 : 0);   // (+ the folded LayerNorm's row statistics)  256x256: 96 KB; 320x256: 108 KB (one workgroup per CU); 256x128: 72 KB (two); 128x128: 48 KB (three); split operand: 256x128 120 KB (one), 128x128 72 KB (two)
     const int dev_slot = current_device_slot();
     if (!attr_set[dev_slot].load(std::memory_order_acquire)) {
-        HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN, BM, STAG, MF, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)gemm256_k<EPI, BN, BM, STAG, MF, SP, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set[dev_slot].store(true, std::memory_order_release);
     }
     dim3 grid((N / BN) * cdiv(M, BM));
-    hipLaunchKernelGGL((gemm256_k<EPI, BN, BM, STAG, MF, SP>), grid, dim3(BM == 128 ? 256 : 512), lds, st, A, lda, W, M, N, K, epi);
+    hipLaunchKernelGGL((gemm256_k<EPI, BN, BM, STAG, MF, SP, NST>), grid, dim3(BM == 128 ? 256 : 512), lds, st, A, lda, W, M, N, K, epi);
     HIP_TRY(hipGetLastError());
     return FY_OK;
 }
@@ -1120,6 +1142,9 @@ static int gemm_launch2(const void* A, int lda, const bf16_t* W, int M, int N, i
         // fewer tiles than that: 128x128 tiles (4 waves, 48 KB, three workgroups per CU); the 16x16x32 form reads a K step's
         // fragments in one go, which costs a workgroup that is alone on its CU more than the clock gains
         if (ov == 2003 || (ov == 0 && 2 * t64 >= 3 * cus)) return gemm_launch_256<EPI, 128, 128, 0, 1>(Ab, lda, W, M, N, K, epi, st);
+        // fewer tiles than CUs (stream=True chunks): one workgroup per CU at most - an eight-stage ring (gemm256_k's comment).  FY_GEMM_DEEP=0: off
+        static const int deep = getenv("FY_GEMM_DEEP") ? atoi(getenv("FY_GEMM_DEEP")) : 1;
+        if (ov == 8128 || (ov == 0 && deep && t64 <= cus && K >= 8 * G2_BK)) return gemm_launch_256<EPI, 128, 128, 0, 0, 0, 8>(Ab, lda, W, M, N, K, epi, st);
         return gemm_launch_256<EPI, 128, 128>(Ab, lda, W, M, N, K, epi, st);
     }
     return gemm_launch3<PRECISE, EPI, 128>(A, lda, W, M, N, K, epi, st);

@@ -44,6 +44,34 @@ int main(int argc, char** argv) {
         {6400, 1024, 2048, 1, "ff2  gate-resid"}, {6400, 1024, 1024, 0, "out-shape bf16 out"}, {1280, 1024, 1024, 0, "M=1280 bf16 out"},
         {12800, 1024, 1024, 0, "M=12800 bf16 out"}, {12800, 3072, 1024, 0, "M=12800 qkv"}, {12800, 2048, 1024, 0, "M=12800 ff1"}, {3200, 3072, 1024, 0, "M=3200 qkv"}, {3200, 1024, 1024, 1, "M=3200 out"}, {3200, 1024, 2048, 1, "M=3200 ff2"}, {6400, 1024, 320, 2, "in-proj f32 out"}};
     extern int gemm_tile_override;
+    if (argc > 1 && !strcmp(argv[1], "small")) {
+        // stream=True sizes: 100 new rows of an incremental chunk, 612 rows of a first chunk (5 s prompt).  Tile 3: the three-stage ring of
+        // 128x128 tiles; 8128: the same with eight stages (what the automatic choice takes below one tile per CU).  Bits must agree.
+        struct S2 { int M, N, K, mode; const char* name; } sm[] = {
+            {100, 3072, 1024, 0, "qkv"}, {100, 1024, 1024, 1, "out"}, {100, 2048, 1024, 0, "ff1"}, {100, 1024, 2048, 1, "ff2"},
+            {612, 3072, 1024, 0, "qkv"}, {612, 1024, 1024, 1, "out"}, {612, 2048, 1024, 0, "ff1"}, {612, 1024, 2048, 1, "ff2"},
+            {1600, 3072, 1024, 0, "qkv"}, {1600, 1024, 2048, 1, "ff2"}};
+        for (auto& q : sm) {
+            std::vector<uint32_t> keep;
+            for (int tile : {3, 8128, 0}) {
+                gemm_tile_override = tile;
+                GemmEpi e; e.bias = bias;
+                if (q.mode == 1) { e.mode = EPI_GATE_RESID; e.resid = R; e.gate = bias; e.ldc = q.N; }
+                else { e.out = O; e.out_bf16 = 1; e.ldc = q.N; e.act = q.N == 2048 ? ACT_GELU_TANH : ACT_NONE; }
+                hipMemsetAsync(R, 0, (size_t)q.M * q.N * 4, st); hipMemsetAsync(O, 0, (size_t)q.M * q.N * 2, st);
+                gemm_bf16(A, q.K, W, q.M, q.N, q.K, e, st);
+                hipStreamSynchronize(st);
+                std::vector<uint32_t> got((size_t)q.M * q.N * (q.mode == 1 ? 4 : 2) / 4);
+                hipMemcpy(got.data(), q.mode == 1 ? (void*)R : (void*)O, got.size() * 4, hipMemcpyDeviceToHost);
+                size_t bad = 0;
+                if (keep.empty()) keep = got; else for (size_t i = 0; i < got.size(); ++i) bad += got[i] != keep[i];
+                int turn = 0;
+                float us = time_loop(st, 48, [&] { gemm_bf16(A, q.K, W + (size_t)(turn++ % NW) * Nmax * Kmax, q.M, q.N, q.K, e, st); });
+                printf("%-4s M %5d N %4d K %4d tile %4d : %7.2f us   %zu words differ from tile 3%s\n", q.name, q.M, q.N, q.K, tile, us, bad, bad ? "  <-- MISMATCH" : "");
+            }
+        }
+        return 0;
+    }
     if (pmc) g_warm = 1;
     if (!pmc) {   // every tiling accumulates K in the same order: the outputs must be bit-identical to the automatic choice's
         for (auto& s : shapes) {
