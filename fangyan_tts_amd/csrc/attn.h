@@ -8,6 +8,9 @@
 int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st, int q_begin = 0,
                   bool interleaved = false);
 
+// the default kernel behind dit_attention (attn_dit.hip): row t of sequence s at row s * seq_rows + t * row_step
+int dit_attention2(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st, int q_begin, int seq_rows, int row_step);
+
 // The split-operand form (fp32-class flow decoder): q, k, v and the output as x = hi + lo, two bf16 planes each, same layouts;
 // three MFMAs per product keep the hi x hi, hi x lo and lo x hi terms, softmax in fp32.
 int dit_attention_split(const bf16_t* qkv_hi, const bf16_t* qkv_lo, bf16_t* out_hi, bf16_t* out_lo, const int* seq_len, int nseq, int Tmax, int H, int chunk,

@@ -199,6 +199,7 @@ __global__ __launch_bounds__(AT_NW * 64) __attribute__((amdgpu_waves_per_eu(WPE,
         }
 }
 
+
 int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, int Tmax, int H, int chunk, hipStream_t st, int q_begin, bool interleaved) {
     FY_CHECK(qkv && out && seq_len && nseq >= 1 && Tmax >= 1 && H >= 1, FY_ERR_ARG, "dit_attention: bad arguments");
     const float sl2 = 0.125f * 1.4426950408889634f;
@@ -215,8 +216,12 @@ int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, 
     // workgroups cover at least half the CUs, one workgroup takes all of a pair's queries (4 waves per SIMD, Q fragments in LDS):
     // K/V are staged once per pair and the grid is a single round - 27.5 us (rocprofv3 over bench.py --no-pipeline).  From 8 waves
     // on the form needs no spill at 128 registers.
-    const int nw = cdiv(Tmax, 32);
     const int seq_rows = interleaved ? 1 : Tmax, row_step = interleaved ? nseq : 1;
+    static const int v1 = getenv("FY_ATTN_V1") ? atoi(getenv("FY_ATTN_V1")) : 0;            // the round-2 kernels (A/B measurements)
+    if (!v1) {
+        return dit_attention2(qkv, out, seq_len, nseq, Tmax, H, chunk, st, q_begin, seq_rows, row_step);
+    }
+    const int nw = cdiv(Tmax, 32);
     int W = 4;                                                   // waves per workgroup
     if (force) W = force;
     else if (nw >= 8 && nw <= 16 && H * nseq >= cus / 2 && q_begin == 0) W = nw;

@@ -281,19 +281,23 @@ def test_tts_speed(tiny):
     assert eng.speed(mel.to(DEV), 1.3).shape[2] == int(41 / 1.3)
 
 
-@pytest.mark.parametrize("T,lens,other_form", [
-    (300, [300, 287, 150, 300, 33, 300, 256, 1], "4"),          # one 10-wave workgroup per (sequence, head) against the 4-wave form
-    (512, [512, 449, 448, 512, 65, 512, 500, 1], "4"),          # 16 waves
+@pytest.mark.parametrize("T,lens,other_env,exact", [
+    # the round-5 kernel (attn_dit.hip: 64 queries per wave, eight-wave workgroups) against the round-2 kernels: two independent
+    # implementations of the same attention (other tilings, half-tile against whole-tile maxima, denominators summed over the bf16
+    # probabilities against the fp32 ones) - the estimator outputs agree to bf16 noise
+    (300, [300, 287, 150, 300, 33, 300, 256, 1], {"FY_ATTN_V1": "1"}, False),
+    (512, [512, 449, 448, 512, 65, 512, 500, 1], {"FY_ATTN_V1": "1"}, False),
+    (650, [650, 611, 333, 650, 1, 650, 640, 97], {"FY_ATTN_V1": "1"}, False),          # the four-wave form of the round-5 kernel
+    # the two workgroup forms of the round-2 kernels walk a query's key tiles in the same order: bit for bit
+    (300, [300, 287, 150, 300, 33, 300, 256, 1], {"FY_ATTN_V1": "1", "FY_ATTN_WAVES": "4"}, True),
 ])
-def test_attention_workgroup_forms_agree(T, lens, other_form, tmp_path):
-    """dit_attention picks one workgroup per (sequence, head) when those cover the chip (batch >= 4 at full size) and 4-wave
-    workgroups otherwise; both walk a query's key tiles in the same order, so the estimator's output must be identical bit for
-    bit - checked on ragged lengths (dead waves, the masked last tile), plain and with the chunk mask, the other form forced
-    through FY_ATTN_WAVES in a child process (the choice is read once per process)."""
+def test_attention_workgroup_forms_agree(T, lens, other_env, exact, tmp_path):
+    """dit_attention's kernels against each other on ragged lengths (dead waves, the masked last tile), plain and with the chunk
+    mask; the other kernel is selected through the environment in a child process (the choice is read once per process).  With
+    exact=True the parent runs the round-2 kernels too (one workgroup per (sequence, head)) and the outputs must be identical."""
     import os
     import subprocess
     import sys
-    eng, _, _ = make(FlowCfg(), max_batch=4, max_frames=T)
     B2 = 8
     g = lambda name, shape: torch.from_numpy(synth.normal(f"in.attnforms.{name}", shape))
     x, mu, cond, spks = g("x", (B2, 80, T)), g("mu", (B2, 80, T)), g("cond", (B2, 80, T)), g("spks", (B2, 80))
@@ -301,8 +305,6 @@ def test_attention_workgroup_forms_agree(T, lens, other_form, tmp_path):
     mask = torch.zeros(B2, 1, T)
     for b, n in enumerate(lens):
         mask[b, 0, :n] = 1
-    d = lambda z: z.to(DEV)
-    here = [eng.estimator(d(x), d(mask), d(mu), d(t), d(spks), d(cond), streaming=s).cpu().numpy() for s in (False, True)]
     script = f"""
 import numpy as np, torch, sys
 sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
@@ -312,16 +314,26 @@ eng, _, _ = tf.make(FlowCfg(), max_batch=4, max_frames={T})
 z = np.load({str(tmp_path / 'in.npz')!r})
 d = lambda k: torch.from_numpy(z[k]).to(tf.DEV)
 out = [eng.estimator(d('x'), d('mask'), d('mu'), d('t'), d('spks'), d('cond'), streaming=s).cpu().numpy() for s in (False, True)]
-np.savez({str(tmp_path / 'out.npz')!r}, plain=out[0], stream=out[1])
+np.savez(sys.argv[1], plain=out[0], stream=out[1])
 """
     np.savez(tmp_path / "in.npz", x=x.numpy(), mask=mask.numpy(), mu=mu.numpy(), t=t.numpy(), spks=spks.numpy(), cond=cond.numpy())
-    env = dict(os.environ, FY_ATTN_WAVES=other_form, PYTHONPATH=os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path))
-    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    other = np.load(tmp_path / "out.npz")
-    for b, n in enumerate(lens):                          # rows past a sequence's length are not defined
-        assert np.array_equal(here[0][b, :, :n], other["plain"][b, :, :n]), b
-        assert np.array_equal(here[1][b, :, :n], other["stream"][b, :, :n]), b
+    base = {k: v for k, v in os.environ.items() if not k.startswith("FY_ATTN_")}
+    base["PYTHONPATH"] = os.pathsep.join([os.path.dirname(os.path.dirname(os.path.abspath(__file__)))] + sys.path)
+    outs = []
+    for name, extra in (("a", {"FY_ATTN_V1": "1"} if exact else {}), ("b", other_env)):
+        r = subprocess.run([sys.executable, "-c", script, str(tmp_path / f"out_{name}.npz")], env=dict(base, **extra), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(tmp_path / f"out_{name}.npz"))
+    for key in ("plain", "stream"):
+        for b, n in enumerate(lens):                      # rows past a sequence's length are not defined
+            u, v = outs[0][key][b, :, :n], outs[1][key][b, :, :n]
+            assert np.isfinite(u).all() and np.isfinite(v).all(), (key, b)
+            if exact:
+                assert np.array_equal(u, v), (key, b)
+            else:
+                # measured 0.9e-2 .. 1.4e-2 on outputs of magnitude ~4 (22 blocks of bf16 attention each way)
+                print(f"attention kernels T={T} {key} seq {b}: max |a - b| = {float(np.abs(u - v).max()):.3e} (max |a| {float(np.abs(u).max()):.2f})")
+                assert float(np.abs(u - v).max()) <= 2.5e-2, (key, b, float(np.abs(u - v).max()))
 
 
 @pytest.mark.parametrize("T,B2,lens", [
