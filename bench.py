@@ -25,7 +25,7 @@ one-batch-at-a-time figure beside the headline (`value_batch8_unpipelined`) and 
 (`value_fresh_inputs`).  `roofline` is the kernel family with the largest GPU-time share of the timed region (the DiT linears),
 measured in the timed configuration with HIP events on the launch stream - per launch as the contract defines it, plus
 `chip_level` (two launches share the chip) and `one_step_alone`; `roofline_lm` the LM's decode; every `traffic` comes from `rocprofv3 --pmc` over this very
-program (profiles/r04_bench_pmc.json; tests/micro/prof_r04.sh).  Secondary objects: `precise_mode`, `latency_b1`, `first_chunk`,
+program (profiles/r05_bench_pmc.json; tests/micro/prof_r05.sh).  Secondary objects: `precise_mode`, `latency_b1`, `first_chunk`,
 `zero_shot_b4` (configs[2]), `hift_cfg5` (configs[4], output checked), `cpu_baseline`, `checked`.
 
 Prints ONE JSON line (rank 0).
@@ -178,9 +178,9 @@ def _pmc(name, *keys):
 
 def dit_roofline(ms, flops, n, where, traffic):
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    return {"bound": "mfma", "kernel": "DiT linears: gemm256_k (LDS-DMA ring; per shape 320x256 tiles with staggered wave groups, 256x128 or 128x128 tiles on 16x16x32 MFMAs)",
+    return {"bound": "mfma", "kernel": "DiT linears: gemm64_k (qkv, ff1: 64-deep register-staged stages, 320x256 / 256x256 tiles, LayerNorm-modulate folded in) and gemm256_k (out-projection, ff2: LDS-DMA ring, 128x128 tiles, gated fp32 residual epilogue), 16x16x32 MFMAs",
             "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-            "traffic_unit": "HBM-side bytes per launch, mean over every gemm256_k launch of the run (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over bench.py itself, separate passes: profiles/r04_bench_pmc.json)",
+            "traffic_unit": "HBM-side bytes per launch, mean over every gemm64_k / gemm256_k launch of the run (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE over bench.py itself, separate passes: profiles/r05_bench_pmc.json, families.dit_linears)",
             "launches": n, "avg_launch_us": round(1e3 * ms / max(n, 1), 2), "gflop_per_launch": round(flops / max(n, 1) / 1e9, 3), "measured_over": where}
 
 
@@ -514,7 +514,7 @@ def main():
     # launched on) around every launch of one kernel family per pass - the DiT linears on the flow stream, then the LM's
     # decode products on the LM stream.  Not inside the timed pass itself: two event records per launch cost the recorded
     # stream a few per cent.  Event-to-event intervals of a kernel that shares the chip include the time its workgroups wait
-    # for CUs the other stream holds, exactly as rocprofv3's begin/end stamps do (profiles/r04_bench_kernel_stats.csv).
+    # for CUs the other stream holds, exactly as rocprofv3's begin/end stamps do (profiles/r05_bench_kernel_stats.csv).
     def events_pass(name):
         L.fy_prof_reset()
         L.fy_prof_only(name.encode())
@@ -543,8 +543,8 @@ def main():
 
     where_t = (f"HIP events on the launch stream around every launch, over a repeat of the {a.steps} timed steps in the timed configuration "
                f"(pipelined: {pipelined})")
-    roofline = dit_roofline(ms_t, flops_t, n_t, where_t, _pmc("r04_bench_pmc.json", "kernels", "gemm256_k", "traffic_bytes"))
-    roofline["why_this_kernel"] = ("the kernel family with the largest share of GPU time in the timed region (profiles/r04_bench_kernel_stats.csv); "
+    roofline = dit_roofline(ms_t, flops_t, n_t, where_t, _pmc("r05_bench_pmc.json", "families", "dit_linears", "traffic_bytes"))
+    roofline["why_this_kernel"] = ("the kernel family with the largest share of GPU time in the timed region (profiles/r05_bench_kernel_stats.csv); "
                                    "bound MFMA: 2 M N K flop per launch, SURVEY 8(d)")
     n_side = a.flow_workers if pipelined else 1
     if n_side > 1 and union_t > 0:
@@ -595,8 +595,8 @@ def main():
         kname = f"LM decode products at {BATCH * G} rows per weight pass: gemv32_k (qkv, o-proj, gate/up, down of 24 layers + llm_decoder; 97 launches per token step)"
     roofline_lm = {"bound": "hbm", "kernel": kname,
                    "achieved": round(gb_t, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gb_t / PEAK_HBM_GBPS, 4),
-                   "traffic": _pmc("r04_bench_pmc.json", "kernels", "llm_decode32_k" if lm32 else "gemv32_k", "traffic_bytes"),
-                   "traffic_unit": "HBM-side bytes per launch, mean over every launch of the run (rocprofv3 --pmc over bench.py itself: profiles/r04_bench_pmc.json)",
+                   "traffic": _pmc("r05_bench_pmc.json", "kernels", "llm_decode32_k" if lm32 else "gemv32_k", "traffic_bytes"),
+                   "traffic_unit": "HBM-side bytes per launch, mean over every launch of the run (rocprofv3 --pmc over bench.py itself: profiles/r05_bench_pmc.json)",
                    "launches": n_vt, "avg_launch_us": round(1e3 * ms_vt / max(n_vt, 1), 2), "algorithmic_bytes_per_launch": int(bytes_vt / max(n_vt, 1)),
                    "measured_over": where_t,
                    "one_generation_alone": alone32 if lm32 else alone_ops,
@@ -621,8 +621,8 @@ def main():
         roofline_lm_p = {"bound": "hbm", "kernel": "llm_decode_k: one persistent launch per token step (24 layers + llm_decoder, 152 workgroups, "
                          "weights register-resident a layer ahead, 121 grid-wide hand-offs)", "achieved": round(gb, 1), "peak": PEAK_HBM_GBPS,
                          "unit": "GB/s", "frac": round(gb / PEAK_HBM_GBPS, 4),
-                         "traffic": _pmc("r04_bench_pmc.json", "kernels", "llm_decode_k", "traffic_bytes"),
-                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc over bench.py itself: profiles/r04_bench_pmc.json, kernels.llm_decode_k.traffic_bytes)",
+                         "traffic": _pmc("r05_bench_pmc.json", "kernels", "llm_decode_k", "traffic_bytes"),
+                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc over bench.py itself: profiles/r05_bench_pmc.json, kernels.llm_decode_k.traffic_bytes)",
                          "launches": n_p, "avg_launch_us": round(1e3 * ms_p / max(n_p, 1), 1), "algorithmic_bytes_per_launch": int(bytes_p / max(n_p, 1)),
                          "generate_ms_batch8_75_tokens": round(lm_p_ms, 2),
                          "measured_over": "HIP events on the launch stream around every launch of one 75-token generation at batch 8, run alone"}

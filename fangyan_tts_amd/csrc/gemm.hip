@@ -314,8 +314,13 @@ __device__ __forceinline__ void ring_ln_rows(char* smem, int ln_off, const GemmE
         double s1 = 0.0, s2 = 0.0;
 #pragma unroll 4
         for (int k = 0; k < n_slots; ++k) { const float2 v = sp[k]; s1 += (double)v.x; s2 += (double)v.y; }
-        const double mean = s1 / e.ln_dim, var = fmax(s2 / e.ln_dim - mean * mean, 0.0);
-        reinterpret_cast<float2*>(smem + ln_off)[r] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-6)));
+        // (one double reciprocal per thread; the root as v_rsq_f32 + one Newton step: a thread's statistics sit before its workgroup's K
+        // loop, and the two double divisions + double root this replaces cost every qkv / ff1 launch 2-3 us)
+        const double inv = 1.0 / (double)e.ln_dim, mean = s1 * inv, var = fmax(s2 * inv - mean * mean, 0.0);
+        const float v = (float)(var + 1e-6);
+        float rs = __builtin_amdgcn_rsqf(v);
+        rs = rs * (1.5f - 0.5f * v * rs * rs);
+        reinterpret_cast<float2*>(smem + ln_off)[r] = make_float2((float)mean, rs);
     }
 }
 
@@ -937,7 +942,6 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm64_k(const bf16_t* __restrict_
     const int m0 = (wg / ntn) * BM, n0 = (wg % ntn) * BN;
     G2_STAMP(0);
     constexpr int LN_OFF = 2 * STAGE;                                   // behind the two buffers (the launcher adds BM x 8 bytes for it)
-    if constexpr (EPI == 0 || EPI == 1) { if (e.ln_rows_slots) ring_ln_rows(smem, LN_OFF, e, M, m0, BM, tid, NT); }
     // staging: load i of a thread is chunk (tid & 7) of row (tid >> 3) + 128 i of the stage (rows 0 .. BM-1: A, then W).  Sources as a
     // wave-uniform base + one 32-bit byte offset per load (64-bit pointers would not fit the 128 registers), destination offset in LDS
     const char* const Abase = reinterpret_cast<const char*>(A + (long)m0 * lda);
@@ -1017,6 +1021,9 @@ __global__ __launch_bounds__(NWAVE * 64) void gemm64_k(const bf16_t* __restrict_
         }
     };
     { G64_LOAD_STAGE(0) }
+    // the folded LayerNorm's row statistics: their loads go out BEHIND the first stage's and land with it (in front of them they were a
+    // second memory latency at the head of every workgroup)
+    if constexpr (EPI == 0 || EPI == 1) { if (e.ln_rows_slots) ring_ln_rows(smem, LN_OFF, e, M, m0, BM, tid, NT); }
     { G64_STORE_STAGE(0) }
     { G64_LOAD_STAGE(min(1, nt - 1)) }
     __syncthreads();
