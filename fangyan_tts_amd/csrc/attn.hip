@@ -230,7 +230,8 @@ int dit_attention(const bf16_t* qkv, bf16_t* out, const int* seq_len, int nseq, 
         hipLaunchKernelGGL((dit_attention_k<4, 3>), grid, dim3(4 * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2, q_begin, seq_rows, row_step);
     } else {
         dim3 grid(cdiv(nw, W), H, nseq);
-#define FY_ATT_CASE(N) case N: hipLaunchKernelGGL((dit_attention_k<N, 4>), grid, dim3(N * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2, q_begin, seq_rows, row_step); break;
+        // (9-12 waves do not fit four per SIMD without spilling - the compiler said so on every build - and never ran at more than three)
+#define FY_ATT_CASE(N) case N: hipLaunchKernelGGL((dit_attention_k<N, (N >= 9 && N <= 12) ? 3 : 4>), grid, dim3(N * 64), 0, st, qkv, out, seq_len, Tmax, H, chunk, sl2, q_begin, seq_rows, row_step); break;
         switch (W) {
             FY_ATT_CASE(8) FY_ATT_CASE(9) FY_ATT_CASE(10) FY_ATT_CASE(11) FY_ATT_CASE(12)
             FY_ATT_CASE(13) FY_ATT_CASE(14) FY_ATT_CASE(15) FY_ATT_CASE(16)

@@ -4,8 +4,9 @@ fmax None = sr/2, center=False), CosyVoice/third_party/Matcha-TTS/matcha/utils/a
 
 Pinning: the STFT is torch.stft itself, called as the reference calls it (audio.py:64-76).  The mel filterbank is
 librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) with librosa's defaults (htk=False, norm="slaney"); librosa is NOT in
-this image and not vendored, so `slaney_mel_filterbank` restates its published definition - PARITY UNPINNED for that table
-(the reference holds no test vector for it either).
+this image and not vendored, so `slaney_mel_filterbank` restates its published definition.  The reference holds no test vector
+for it; the table is held to an INDEPENDENT port of the same definition, transformers.audio_utils.mel_filter_bank(norm="slaney",
+mel_scale="slaney"), to 2e-9 (tests/test_independent_ports_cpu.py) - pinned to a port, not to librosa itself.
 """
 import numpy as np
 import torch
@@ -48,8 +49,11 @@ def mel_spectrogram(y: torch.Tensor, n_fft: int = 1920, num_mels: int = 80, samp
 
 # ---- the 16 kHz features of the reference's two ONNX models (cli/frontend.py:94-117) -----------------------------------------
 # whisper (openai-whisper, whisper/audio.py:log_mel_spectrogram) and torchaudio (torchaudio/compliance/kaldi.py:fbank) are NOT in
-# this image and not vendored by the reference: both are restated from their published algorithms - PARITY UNPINNED.  The
-# transforms themselves are torch.stft / torch.fft.rfft, called as those libraries call them.
+# this image and not vendored by the reference: both are restated from their published algorithms.  Neither library can be imported
+# here; the restatements are held to independent ports of the same algorithms in transformers (tests/test_independent_ports_cpu.py):
+# WhisperFeatureExtractor's numpy extraction (1e-5) and SeamlessM4TFeatureExtractor's "numpy method to mimic Kaldi" (1.4e-4 in the
+# log domain after its 2^15 waveform scale) - pinned to ports, not to the libraries themselves.  The transforms are torch.stft /
+# torch.fft.rfft, called as those libraries call them.
 
 def whisper_log_mel(audio: torch.Tensor, n_mels: int = 128) -> torch.Tensor:
     """audio (1, S) at 16 kHz -> (1, n_mels, S // 160): hann(400), stft(400, hop 160, center, reflect), |.|^2 of all frames but the
