@@ -159,13 +159,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[q][r] = (r & 3) + 8 * (r >> 2) < visn ? sc[q][r] : -1e30f;
     };
-    // row maxima of block q's fresh scores: the running maximum moves, and everything summed so far shrinks by alpha
-    // (rarely: the maxima settle after a few tiles)
-    auto row_max = [&](auto qc) {
+    // Row maxima of block q's fresh scores in two pieces (both ride behind the stage's first MFMAs, which belong to the OTHER block):
+    // the lane's maximum as a tree of v_max3 (depth 3: a serial chain of 15 cost its latency before every stage), then the exchange
+    // with the other half-wave; the running maximum moves, and everything summed so far shrinks by alpha (rarely: the maxima settle
+    // after a few tiles)
+    auto row_max_lane = [&](auto qc) -> float {
         constexpr int q = decltype(qc)::value;
-        float mx = sc[q][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[q][r]);
+        const f32x16& v = sc[q];
+        auto m3 = [](float a, float b, float c) { return fmaxf(fmaxf(a, b), c); };
+        const float t0 = m3(v[0], v[1], v[2]), t1 = m3(v[3], v[4], v[5]), t2 = m3(v[6], v[7], v[8]), t3 = m3(v[9], v[10], v[11]), t4 = m3(v[12], v[13], v[14]);
+        return m3(m3(t0, t1, t2), m3(t3, t4, v[15]), t0);
+    };
+    auto row_max_update = [&](auto qc, float mx) {
+        constexpr int q = decltype(qc)::value;
         float a, b;
         xhalf(mx, a, b);
         mx = fmaxf(a, b) * scale_log2;
@@ -213,32 +219,44 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         static_for<NQ>([&](auto sc_) {
             constexpr int st_ = decltype(sc_)::value;                   // stage: block st_'s exponents, block st_ - 1's MFMAs, block st_ - 2's maxima
             constexpr int qa = (st_ + NQ - 1) % NQ, qb = (st_ + NQ - 2) % NQ, par = st_ & 1;
-            // (the first two stages of the first body have nothing behind them: the prologue took those maxima)
-            if constexpr (!(first && st_ < 2)) {
-                // block qb's scores: of half tile hh + 1 when its MFMAs ran in this body (stages 2 ..), of half tile hh otherwise
-                if (st_ >= 2 ? mask_next : mask_cur) mask_scores(std::integral_constant<int, qb>{}, st_ >= 2 ? kb + 32 : kb);
-                if (AT2_ABL != 5) row_max(std::integral_constant<int, qb>{});
-            }
-            float mq = m_run[st_];
-            float ps = 0.f;
-            asm volatile("" : "+v"(mq));                     // (opaque: the exponents' arguments are computed in their slices, not a block early)
-            SB();
+            // (the first two stages of the first body have no maxima to take: the prologue took them)
+            constexpr bool maxima = !(first && st_ < 2) && AT2_ABL != 5;
+            float mq = m_run[st_], mx_lane = 0.f, ps = 0.f;
             // slice e of the exponent work: two probabilities, registers 2 e and 2 e + 1
             auto e2 = [&](auto ic) {
                 constexpr int e = decltype(ic)::value;
-                if constexpr (e < 8) {
 #pragma unroll
-                    for (int r = 2 * e; r < 2 * e + 2; ++r) {
-                        const float p = AT2_ABL == 1 ? fmaf(sc[st_][r], scale_log2, -mq) : __builtin_amdgcn_exp2f(fmaf(sc[st_][r], scale_log2, -mq));
-                        if constexpr (!ONES) ps += p;
-                        pf[par][r >> 3][r & 7] = (__bf16)p;
-                    }
+                for (int r = 2 * e; r < 2 * e + 2; ++r) {
+                    const float p = AT2_ABL == 1 ? fmaf(sc[st_][r], scale_log2, -mq) : __builtin_amdgcn_exp2f(fmaf(sc[st_][r], scale_log2, -mq));
+                    if constexpr (!ONES) ps += p;
+                    pf[par][r >> 3][r & 7] = (__bf16)p;
                 }
             };
+            // the vector work behind MFMA i of the stage (the MFMAs are block qa's; everything here is block st_'s): the maxima of its
+            // fresh scores behind the first two - block st_'s scores are of half tile hh + 1 when its MFMAs ran in this body (stages
+            // 2 ..), of half tile hh otherwise - then the eight exponent slices, one per MFMA
+            auto valu = [&](auto ic) {
+                constexpr int i = decltype(ic)::value, n_mfma = (ONES ? 6 : 4) + 4;
+                if constexpr (i == 0) {
+                    if constexpr (maxima) {
+                        if (st_ >= 2 ? mask_next : mask_cur) mask_scores(std::integral_constant<int, qb>{}, st_ >= 2 ? kb + 32 : kb);
+                        mx_lane = row_max_lane(std::integral_constant<int, qb>{});
+                    }
+                } else if constexpr (i == 1) {
+                    if constexpr (maxima) row_max_update(std::integral_constant<int, qb>{}, mx_lane);
+                    mq = m_run[st_];
+                    asm volatile("" : "+v"(mq));             // (opaque: the exponents' arguments are computed in their slices, not a block early)
+                } else {
+                    e2(std::integral_constant<int, i - 2>{});
+                    if constexpr (i == n_mfma - 1) static_for<8 - (n_mfma - 2)>([&](auto jc) { e2(std::integral_constant<int, n_mfma - 2 + decltype(jc)::value>{}); });
+                }
+            };
+            static_assert(qb == st_ % NQ || NQ != 2, "two blocks per wave: the maxima are the block's whose exponents follow");
             if constexpr (first && st_ == 0) {
+                asm volatile("" : "+v"(mq));
                 static_for<8>(e2);
             } else {
-                mfma_stage(std::integral_constant<int, qa>{}, std::integral_constant<int, par ^ 1>{}, std::true_type{}, e2);
+                mfma_stage(std::integral_constant<int, qa>{}, std::integral_constant<int, par ^ 1>{}, std::true_type{}, valu);
             }
             // (P is complete HERE: without a use the compiler sinks the exponent slices into the next stage, beside ITS slices, and this
             // stage's MFMAs run bare)
@@ -268,7 +286,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int q = 0; q < NQ; ++q) sc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[q][ks], ks == 0 ? z16 : sc[q], 0, 0, 0);
-        static_for<NQ>([&](auto qc) { mask_scores(qc, 0); row_max(qc); });
+        static_for<NQ>([&](auto qc) { mask_scores(qc, 0); row_max_update(qc, row_max_lane(qc)); });
     }
     int kslot = 0;                                           // ring slot of K(t)
     for (int t = 0; t < NTL; ++t) {
