@@ -60,6 +60,7 @@ struct fy_flow {
     bf16_t* inc_qkv = nullptr;
     float* inc_x = nullptr;
     int inc_T = 0;
+    int inc_np = -1, inc_npf = -1, inc_ntok = -1;       // the stream's prompt tokens / prompt frames / tokens at the last kept call (a cheap check that a call extends it)
     ~fy_flow() { conv_free(pre1); conv_free(pre2); conv_free(pos1); conv_free(pos2); }
 };
 
@@ -804,6 +805,10 @@ extern "C" int fy_flow_infer(fy_flow* f, const int32_t* token, int32_t tok_ld, c
     if (inc) {
         int T0 = f->inc_T;
         if (T0 % c.static_chunk != 0 || T0 >= Tmax) T0 = 0;
+        // a call extends the stream only with the same prompt and at least the tokens it had (a caller that forgot fy_flow_stream_reset
+        // between two utterances would otherwise attend the previous utterance's keys): anything else starts over
+        if (n_prompt[0] != f->inc_np || n_pfeat[0] != f->inc_npf || n_token[0] < f->inc_ntok) T0 = 0;
+        f->inc_np = n_prompt[0]; f->inc_npf = n_pfeat[0]; f->inc_ntok = n_token[0];
         float* xs = f->inc_x;
         const size_t xslice = (size_t)f->Tmax * C;
         for (int step = 0; step < c.n_timesteps; ++step) {

@@ -67,8 +67,10 @@ int fy_stream_destroy(void* stream);
 #define FY_INCREMENTAL 16u /* flow, with FY_STREAMING | FY_NO_FINALIZE and B = 1: this call extends the previous FY_INCREMENTAL call of the
                              handle (same prompt, the earlier tokens a prefix): only the new rows go through the DiT blocks, against the
                              keys / values of the earlier rows kept per (Euler step, block).  Exact under the chunk mask when both calls end
-                             on a chunk boundary (the reference's schedule does); otherwise, and after fy_flow_stream_reset, everything is
-                             computed (and kept).  Same results as without the flag.                                                    */
+                             on a chunk boundary (the reference's schedule does).  After fy_flow_stream_reset, when the prompt lengths differ
+                             from the previous call's or the token count shrank, everything is computed and kept for the next call; a call
+                             whose length is not a whole number of chunks is computed whole and keeps NOTHING (the next call starts over).
+                             Same results as without the flag.                                                                         */
 #define FY_NO_FINALIZE 8u /* flow, HiFT: a streaming chunk (finalize=False in the reference): the last tokens / frames are
                             look-ahead context, not output (flow: pre_lookahead tokens; HiFT: 3 + 4 frames and 480 samples) */
 

@@ -218,3 +218,14 @@ def test_flow_incremental_chunks_equal_full_recompute():
     n_in = 3 * hop + look
     args = (token[:, :n_in].contiguous(), [n_in], ptoken, [p_tok], pfeat, [2 * p_tok], emb, noise)
     assert torch.equal(eng.inference(*args, streaming=True, finalize=False, incremental=True), ref.inference(*args, streaming=True, finalize=False))
+    # a caller that forgets stream_reset between two utterances: another prompt (here 25 tokens shorter), or fewer tokens than the stream
+    # already holds, cannot be an extension - the call starts over instead of attending the previous utterance's keys and values
+    assert eng.stream_rows() == 2 * (p_tok + n_in - look)
+    p2 = p_tok - 25
+    token2 = torch.from_numpy(synth.randint("in.flow.token.inc.other", (1, n_max), 0, cfg.vocab))
+    for n_in in (2 * hop + look, 3 * hop + look, hop + look):
+        args = (token2[:, :n_in].contiguous(), [n_in], ptoken[:, :p2].contiguous(), [p2], pfeat[:, :2 * p2].contiguous(), [2 * p2], emb, noise)
+        valid = 2 * (n_in - look)
+        inc = eng.inference(*args, streaming=True, finalize=False, incremental=True)
+        full = ref.inference(*args, streaming=True, finalize=False)
+        assert torch.equal(inc[:, :, :valid], full[:, :, :valid]), n_in
