@@ -53,7 +53,8 @@ int main(int argc, char** argv) {
             {1600, 3072, 1024, 0, "qkv"}, {1600, 1024, 2048, 1, "ff2"}};
         for (auto& q : sm) {
             std::vector<uint32_t> keep;
-            for (int tile : {3, 8128, 0}) {
+            for (int tile : {3, 8128, 0, 6400, 6408, 6432, 6412}) {      // 64xx: the 64-deep register-staged kernel (6412: its 256x128 form for the gated residual products)
+                if ((q.mode == 1) != (tile == 6412) && tile >= 6400) continue;
                 gemm_tile_override = tile;
                 GemmEpi e; e.bias = bias;
                 if (q.mode == 1) { e.mode = EPI_GATE_RESID; e.resid = R; e.gate = bias; e.ldc = q.N; }

@@ -8,4 +8,4 @@ for f in fangyan_tts_amd/csrc/gemm.hip fangyan_tts_amd/csrc/runtime.hip tests/mi
   hipcc $F -c $f -o /tmp/$(basename $f .hip).o 2>/dev/null
 done
 hipcc --offload-arch=gfx950 /tmp/gemm_bench.o /tmp/gemm.o /tmp/runtime.o -o /tmp/gemm_bench
-timeout -k 10 400 /tmp/gemm_bench
+timeout -k 10 400 /tmp/gemm_bench $1
