@@ -288,6 +288,9 @@ def test_tts_speed(tiny):
     (300, [300, 287, 150, 300, 33, 300, 256, 1], {"FY_ATTN_V1": "1"}, False),
     (512, [512, 449, 448, 512, 65, 512, 500, 1], {"FY_ATTN_V1": "1"}, False),
     (650, [650, 611, 333, 650, 1, 650, 640, 97], {"FY_ATTN_V1": "1"}, False),          # the four-wave form of the round-5 kernel
+    # the tiling choice's edges: 257 frames = 9 blocks on the eight-wave form (the last wave half dead), 513 = 17 blocks on 3 x 8 slots
+    (257, [257, 256, 225, 257, 31, 257, 193, 2], {"FY_ATTN_V1": "1"}, False),
+    (513, [513, 512, 481, 513, 257, 513, 33, 7], {"FY_ATTN_V1": "1"}, False),
     # the two workgroup forms of the round-2 kernels walk a query's key tiles in the same order: bit for bit
     (300, [300, 287, 150, 300, 33, 300, 256, 1], {"FY_ATTN_V1": "1", "FY_ATTN_WAVES": "4"}, True),
 ])
